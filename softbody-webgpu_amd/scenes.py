@@ -1,0 +1,118 @@
+"""Synthetic scene generators.
+
+The only "fixtures" the reference has are its default scene and the lattice
+helper that builds it: `addRectangle` in /root/reference/src/main.ts:203-214
+(particle (x,y) at (ox + x*d, oy + y*d), data index x*h + y; beams to +y, +x
+and both diagonals).  These functions generalise that helper.
+"""
+import numpy as np
+
+from .layout import BEAM_DTYPE, LAYOUT_V1, LAYOUT_V2, Buffers
+
+
+def rectangle(ox, oy, d, w, h, spring, damp, yield_strain, strain_limit, *, base=0,
+              anti_diagonal=True, layout=LAYOUT_V2):
+    """Vectorised `addRectangle` (main.ts:203-214).  Returns (particles (w*h,2) f32, beams
+    structured array) with beams in the reference's emission order: for each particle b in
+    index order, [+y, +x, diagonal(+x,+y), anti-diagonal(+x,-y)] where they exist.
+    anti_diagonal=False drops the main.ts:211 beam (the "~3 beams/particle" topology of
+    BASELINE config 2)."""
+    xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")  # index = x*h + y
+    xs = xs.reshape(-1)
+    ys = ys.reshape(-1)
+    # float64 math then one rounding to f32, as JS (doubles) -> Float32Array does
+    pos = np.stack([xs * float(d) + float(ox), ys * float(d) + float(oy)], axis=1).astype("<f4")
+    idx = (xs * h + ys).astype(np.int64) + base
+    kinds = [
+        (ys < h - 1, 1, float(d)),                                  # main.ts:208
+        (xs < w - 1, h, float(d)),                                  # main.ts:209
+        ((ys < h - 1) & (xs < w - 1), h + 1, np.sqrt(2.0) * d),     # main.ts:210
+    ]
+    if anti_diagonal:
+        kinds.append(((ys > 0) & (xs < w - 1), h - 1, np.sqrt(2.0) * d))  # main.ts:211
+    nk = len(kinds)
+    n = w * h
+    valid = np.stack([k[0] for k in kinds], axis=1)          # (n, nk), row-major = emission order
+    a = np.repeat(idx, nk).reshape(n, nk)
+    boff = np.array([k[1] for k in kinds], dtype=np.int64)
+    blen = np.array([k[2] for k in kinds], dtype=np.float64)
+    b = a + boff[None, :]
+    ln = np.broadcast_to(blen[None, :], (n, nk))
+    sel = valid.reshape(-1)
+    beams = np.zeros(int(sel.sum()), dtype=BEAM_DTYPE[layout])
+    beams["a"] = a.reshape(-1)[sel]
+    beams["b"] = b.reshape(-1)[sel]
+    L = ln.reshape(-1)[sel].astype("<f4")
+    beams["length"] = L
+    beams["target_length"] = L   # Beam ctor defaults, engineMapping.ts:170-171
+    beams["last_length"] = L
+    beams["spring"] = spring
+    beams["damp"] = damp
+    beams["yield_strain"] = yield_strain
+    beams["strain_break_limit"] = strain_limit
+    return pos, beams
+
+
+def default_scene(layout=LAYOUT_V1):
+    """`oofDefaultState`, main.ts:188-246: 119 particles / 299 beams."""
+    parts, beams = [], []
+    base = 0
+
+    def add(*args):
+        nonlocal base
+        p, b = rectangle(*args, base=base, layout=layout)
+        parts.append(p)
+        beams.append(b)
+        base += p.shape[0]
+
+    def free(x, y):
+        nonlocal base
+        parts.append(np.array([[x, y]], dtype="<f4"))
+        base += 1
+
+    add(185, 10, 60, 2, 2, 1, 50, 1, 2.5)       # main.ts:218
+    add(35, 10, 60, 2, 2, 1, 50, 1, 2.5)        # :219
+    add(20, 120, 30, 9, 4, 50, 700, 0.2, 0.5)   # :220
+    free(445, 10)                               # :221
+    free(925, 10)                               # :222
+    add(400, 40, 30, 20, 2, 500, 800, 0.1, 0.5) # :223
+    add(700, 400, 40, 5, 5, 3, 50, 2, 5)        # :224
+    add(20, 900, 50, 2, 2, 0.05, 10, 2, 3)      # :240
+    add(20, 700, 50, 2, 2, 0.1, 10, 2, 3)       # :241
+    return np.concatenate(parts), np.concatenate(beams)
+
+
+def default_buffers(layout=LAYOUT_V1, max_particles=None, max_beams=None):
+    p, b = default_scene(layout)
+    buf = Buffers(layout, max_particles or 65536, max_beams or 65536)
+    buf.set_scene(p, b)
+    return buf
+
+
+def lattice_buffers(w, h, d=30.0, origin=(1000.0, 1000.0), spring=50.0, damp=700.0,
+                    yield_strain=0.2, strain_limit=1.0e9, *, anti_diagonal=False,
+                    layout=LAYOUT_V2, jitter=0.0, velocity=None, seed=1, slack=0):
+    """One w x h lattice blob (BASELINE configs 2-5 are instances of this)."""
+    p, b = rectangle(origin[0], origin[1], d, w, h, spring, damp, yield_strain, strain_limit,
+                     anti_diagonal=anti_diagonal, layout=layout)
+    pv = np.zeros((p.shape[0], 6), dtype="<f4")
+    pv[:, :2] = p
+    if jitter:
+        pv[:, :2] += hash_uniform(seed, p.shape[0] * 2).reshape(-1, 2).astype("<f4") * np.float32(jitter)
+    if velocity is not None:
+        pv[:, 2:4] = np.asarray(velocity, dtype="<f4")
+    buf = Buffers(layout, p.shape[0] + slack, b.shape[0] + slack)
+    buf.set_scene(pv, b)
+    return buf
+
+
+def hash_uniform(seed, n):
+    """Documented integer hash -> uniform [-1, 1) doubles (no Math.random).
+    splitmix64 of (seed*2^32 + i)."""
+    x = (np.uint64(seed) << np.uint64(32)) + np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(11)).astype(np.float64) / float(1 << 52) - 1.0
