@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the softbody physics step on MI355X.
+
+One "step" = one substep = one `compute_update` (compute.wgsl:90-203) over the whole scene.
+Workload at N=1: BASELINE config 2 -- one 1000x1000 lattice blob, 1 000 000 particles /
+2 996 001 beams, fp32, wide (v2) layout, collisions off, subticks 64 (dt = 1/64), scene already
+resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1000, help="lattice columns per GPU")
+    ap.add_argument("--height", type=int, default=1000, help="lattice rows")
+    ap.add_argument("--collisions", choices=["off", "grid"], default="off")
+    ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(sb, buf, bounds, mode, budget_s):
+    """Times the oracle (our C restatement of compute.wgsl; the reference has no CPU path) on
+    the same scene for a bounded number of substeps.  Reported beside the GPU, never the target."""
+    import __graft_entry__ as ge
+    orc = ge.load_oracle()
+    orc.build()
+    # the GPU box grants about 16 cores per GPU; more OpenMP threads than that only thrash
+    cores = min(16, len(os.sched_getaffinity(0)))
+    P = buf.particle_count
+    out = {}
+    for label, threads, share in (("single", 1, 0.35), ("all", cores, 0.65)):
+        ref = orc.OracleEngine(bounds, 10.0, 64, buf.layout, mode, threads=threads)
+        ref.write_buffers(buf)
+        t0 = time.perf_counter()
+        ref.step(2)
+        per = (time.perf_counter() - t0) / 2
+        n = max(2, min(2000, int(budget_s * share / max(per, 1e-6)) // 2 * 2))
+        t0 = time.perf_counter()
+        ref.step(n)
+        dt = time.perf_counter() - t0
+        out[label] = dict(value=P * n / dt, substeps=n, seconds=dt, threads=threads)
+    return {
+        "value": out["all"]["value"], "unit": "particle-steps/s", "cores": out["all"]["threads"],
+        "kind": "port",
+        "sample": "oracle/sb_oracle.c (C restatement of compute.wgsl; the reference has no CPU path), same "
+                  "scene, %d substeps in %.1f s with %d OpenMP threads; 1 thread: %.3g particle-steps/s over %d substeps"
+                  % (out["all"]["substeps"], out["all"]["seconds"], out["all"]["threads"],
+                     out["single"]["value"], out["single"]["substeps"]),
+        "single_thread_value": out["single"]["value"],
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    sb = ge.load_package()
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from importlib import import_module
+    halo = import_module("softbody_webgpu_amd.halo") if world > 1 else None
+
+    W, H = a.width, a.height
+    d = 30.0
+    mode = {"off": 0, "grid": 2}[a.collisions]
+    path = {"auto": 0, "atomic": 1, "tiled": 2}[a.path]
+    # global scene: N slabs of W columns side by side (weak scaling: per-GPU work is fixed)
+    bounds = float(max(W * world, H) * d + 2000.0)
+    if world == 1:
+        buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0, layout=2)
+        plan = None
+    else:
+        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0)
+    P_local = buf.particle_count if plan is None else plan.n_owned
+    B_local = buf.beam_count
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=64, layout=2,
+                    max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
+                    path=path, tile_particles=a.tile, device=local)
+    eng.write_buffers(buf)
+    stepper = eng.step if plan is None else halo.Exchanger(sb, eng, plan, dist, torch).step
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    stepper(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    if plan is None:
+        kernel_ms = eng.step_timed(a.steps)   # HIP events on the engine's own stream
+    else:
+        stepper(a.steps)
+        kernel_ms = None
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        cnt = torch.tensor([P_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt)
+        P_total = int(cnt.item())
+    else:
+        P_total = P_local
+
+    if rank == 0:
+        copies = eng.info("beam_copies")
+        alg_bytes = 52.0 * B_local + 48.0 * P_local  # per substep, one launch
+        roof = None
+        if kernel_ms is not None:
+            per_launch_s = kernel_ms * 1e-3 / a.steps
+            ach = alg_bytes / per_launch_s / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "k_substep_tiled" if eng.info("path") == 2 else "k_beams_atomic+k_particles",
+                    "avg_launch_us": per_launch_s * 1e6,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "achieved = (52*B + 48*P) bytes / (HIP-event time of the timed region / steps); "
+                            "beam copies on device: %d for %d beams" % (copies, B_local)}
+        line = {
+            "metric": "particle-steps/sec", "value": P_total * a.steps / wall, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
+                                   "spring 50 damp 700, jitter 1.0, subticks 64, collisions %s, v2 (u32) layout"
+                                   % (W, H, P_local, B_local, a.collisions),
+                       "particles_total": P_total, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
+                       "tiles": eng.info("tiles"),
+                       "parallelism": "single GPU" if world == 1 else "%d x-slabs, ghost p,v exchange per substep over RCCL" % world},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sb, buf, bounds, mode, a.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    eng.destroy()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * softbody.h -- C ABI of the MI355X-native softbody physics step.
+ *
+ * Drop-in boundary for ONE path of spsquared/softbody-webgpu: the per-substep
+ * physics step (`compute_update` / `compute_delete`, src/shaders/compute.wgsl:90-246)
+ * as driven by src/engineWorker.ts.  The reference has no FFI: its boundary is the
+ * set of WebGPU calls engineWorker.ts makes on seven storage buffers, in the byte
+ * layouts src/engineMapping.ts defines.  Each entry point below replaces one of
+ * those call groups (cited per function) and moves raw bytes in those layouts.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an sb_status (0 = ok);
+ *     sb_last_error() gives the message for the last failure on that engine
+ *     (engine == NULL: the last sb_create failure of the calling thread).
+ *   - COPY semantics: no host pointer is retained after a call returns (the JS
+ *     ArrayBuffers are owned and later mutated by BufferMapper,
+ *     engineMapping.ts:364-367).
+ *   - one call at a time per engine, like the reference's AsyncLock
+ *     (src/lock.ts:4-19; engineWorker.ts:553,584,632).  sb_step/sb_frame only
+ *     enqueue work on the engine's HIP stream; sb_sync, sb_load_buffers and
+ *     sb_step_timed wait for it.
+ *   - there is no CPU fallback: without a usable HIP device sb_create fails.
+ */
+#ifndef SOFTBODY_H
+#define SOFTBODY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SB_ABI_VERSION 1
+
+typedef struct sb_engine sb_engine;
+
+typedef enum sb_status {
+    SB_OK = 0,
+    SB_ERR_INVALID = 1,     /* bad argument / buffer too small / inconsistent scene */
+    SB_ERR_HIP = 2,         /* a HIP runtime call failed (message carries hipGetErrorString) */
+    SB_ERR_NO_DEVICE = 3,   /* no usable gfx950 device (engineWorker.ts:86,93,98 throw TypeError) */
+    SB_ERR_OOM = 4,
+    SB_ERR_STATE = 5,       /* call order (e.g. step before write_buffers) */
+    SB_ERR_UNSUPPORTED = 6
+} sb_status;
+
+/* host buffer layouts (src/engineMapping.ts) */
+#define SB_LAYOUT_V1 1 /* reference: u16 mapping, beam = packed u16 pair + 9 f32, stride 40 */
+#define SB_LAYOUT_V2 2 /* wide: u32 mapping, beam = u32 a, u32 b + 9 f32, stride 44 */
+
+/* particle-particle collision broad phase (compute.wgsl:142-170) */
+#define SB_COLLIDE_OFF 0      /* skip the collision loop (BASELINE config 2) */
+#define SB_COLLIDE_ALLPAIRS 1 /* the reference's O(P^2) scan, LDS-tiled */
+#define SB_COLLIDE_GRID 2     /* spatial hash; same pair set and summation order => same bits */
+
+/* device schedule of one substep */
+#define SB_PATH_AUTO 0
+#define SB_PATH_ATOMIC 1 /* beam kernel with global i32 atomics + particle kernel */
+#define SB_PATH_TILED 2  /* fused LDS-tiled substep: forces never leave the CU */
+
+#define SB_METADATA_BYTES 112
+#define SB_PARTICLE_STRIDE 24
+#define SB_BEAM_STRIDE_V1 40
+#define SB_BEAM_STRIDE_V2 44
+#define SB_USER_INPUT_BYTES 32
+#define SB_USER_INPUT_OFFSET 80
+
+typedef struct sb_options {
+    uint32_t struct_size;    /* = sizeof(sb_options) */
+    float bounds_size;       /* engineWorker.ts:39 (fixed 1000 there; an option here) */
+    float particle_radius;   /* engineWorker.ts:40,89 */
+    uint32_t subticks;       /* engineWorker.ts:41,90: rounded UP to even; time_step = 1/subticks (:331) */
+    uint32_t max_particles;  /* capacity; BufferMapper.maxParticles (engineMapping.ts:362) */
+    uint32_t max_beams;      /* capacity; BufferMapper.maxBeams (engineMapping.ts:363) */
+    uint32_t layout;         /* SB_LAYOUT_* */
+    uint32_t collision_mode; /* SB_COLLIDE_* */
+    uint32_t path;           /* SB_PATH_* */
+    uint32_t tile_particles; /* SB_PATH_TILED: target particles per tile (0 = default) */
+    int32_t device_ordinal;  /* HIP device */
+    uint32_t reserved[5];
+} sb_options;
+
+/* Fill with the reference defaults: bounds 1000, radius 10, subticks 64, 65536/65536, v1,
+ * all-pairs, auto path, device 0. */
+void sb_default_options(sb_options *opts);
+
+/* Replaces the WGPUSoftbodyEngineWorker constructor's device/buffer/pipeline creation
+ * (engineWorker.ts:83-176, 312-343). */
+sb_status sb_create(const sb_options *opts, sb_engine **out);
+
+/* engineWorker.ts:711-717 destroy(). */
+sb_status sb_destroy(sb_engine *e);
+
+/* Replaces writeBuffers() (engineWorker.ts:580-597): uploads metadata, mapping, particle data
+ * (-> buffer A) and beam data; zeroes the force accumulators, the delete mask and buffer B.
+ * Buffers are the BufferMapper ArrayBuffers (engineMapping.ts:342-345) at FULL capacity:
+ * metadata 112 B, mapping (max_particles+max_beams) entries, particles max_particles*24 B,
+ * beams max_beams*stride B; the *_bytes arguments are checked against that. */
+sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_bytes,
+                           const void *mapping, size_t mapping_bytes,
+                           const void *particles, size_t particles_bytes,
+                           const void *beams, size_t beams_bytes);
+
+/* Replaces Metadata.writeUserInput (engineMapping.ts:323-325, engineWorker.ts:636-642):
+ * the 32 bytes at metadata offset 80 (user_strength, mouse_active, mouse_pos, mouse_vel,
+ * applied_force). */
+sb_status sb_write_user_input(sb_engine *e, const void *bytes32);
+
+/* Replaces the PHYSICS_CONSTANTS round trip (engineWorker.ts:497-507): the 8 floats at
+ * metadata offset 48 (gravity.xy, border_elasticity, border_friction, elasticity, friction,
+ * drag_coeff, drag_exp), without re-uploading the scene. */
+sb_status sb_set_physics_constants(sb_engine *e, const float constants8[8]);
+sb_status sb_get_physics_constants(sb_engine *e, float constants8[8]);
+
+/* Replaces the compute pass of frame() (engineWorker.ts:646-665): `subticks` x compute_update
+ * with alternating read/write particle buffers, then one compute_delete. */
+sb_status sb_frame(sb_engine *e);
+
+/* n x compute_update only (benchmark granularity: one "step" = one substep).  Any n; the
+ * engine tracks which particle buffer is current. */
+sb_status sb_step(sb_engine *e, uint32_t n_substeps);
+
+/* one compute_delete (compute.wgsl:205-246, canonical semantics: stable compaction). */
+sb_status sb_delete_pass(sb_engine *e);
+
+/* device.queue.onSubmittedWorkDone() (engineWorker.ts:633,687). */
+sb_status sb_sync(sb_engine *e);
+
+/* sb_step bracketed by HIP events on the engine's stream; *ms = device time of the n substeps. */
+sb_status sb_step_timed(sb_engine *e, uint32_t n_substeps, float *ms);
+
+/* Replaces loadBuffers() (engineWorker.ts:548-579): metadata, mapping, particles (current
+ * buffer) and beams back into host ArrayBuffers of full capacity.  Only records reachable
+ * through the mapping are written; other bytes of the caller's buffers are left as they are.
+ * Any pointer may be NULL to skip that buffer. */
+sb_status sb_load_buffers(sb_engine *e, void *metadata, size_t metadata_bytes,
+                          void *mapping, size_t mapping_bytes,
+                          void *particles, size_t particles_bytes,
+                          void *beams, size_t beams_bytes);
+
+/* counts as the device sees them (metadata.particle_i_c / beam_i_c after deletes). */
+sb_status sb_get_counts(sb_engine *e, uint32_t *particles, uint32_t *beams);
+
+/* introspection for benches/tests: key = "path", "tiles", "beam_copies", "halo_particles",
+ * "device_bytes", "substeps_done", "kernels_per_substep". */
+sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value);
+
+/* ---- multi-GPU halo exchange; one engine per rank/GPU.
+ * Ghost particles are particles in this engine's scene that another rank owns: they are
+ * never integrated here; their p,v are overwritten from the owner before every substep.
+ * Lists are DATA indices into this engine's particle buffer. */
+sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_indices, uint32_t n_ghost,
+                            const uint32_t *send_indices, uint32_t n_send);
+/* pack p,v (4 floats each) of the send list from the current particle buffer into a DEVICE
+ * buffer of n_send*16 bytes, on the engine's stream. */
+sb_status sb_halo_pack(sb_engine *e, void *device_dst);
+/* overwrite p,v of the ghost list in the current particle buffer from a DEVICE buffer of
+ * n_ghost*16 bytes, on the engine's stream. */
+sb_status sb_halo_unpack(sb_engine *e, const void *device_src);
+/* the engine's hipStream_t, so a caller can order its own work (RCCL send/recv) after it. */
+sb_status sb_get_stream(sb_engine *e, void **hip_stream);
+
+const char *sb_last_error(const sb_engine *e);
+uint32_t sb_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -31,6 +31,9 @@ def lib():
         path = os.path.join(_HERE, "libsboracle.so")
         if not os.path.exists(path):
             build()
+        # libgomp's default active spinning collapses when the team size changes between calls
+        # (measured here: 8 threads slower than 1); it reads this at load time
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = ctypes.CDLL(path)
         vp = ctypes.c_void_p
         L.sbo_update.argtypes = [ctypes.POINTER(_Params), vp, vp, vp, vp, vp, vp, vp]

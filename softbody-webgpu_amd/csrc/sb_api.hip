@@ -1,0 +1,659 @@
+// sb_api.hip -- the C ABI of include/softbody.h: host driver of the HIP substep.
+//
+// Plays the role src/engineWorker.ts plays in the reference (device + buffers + subtick loop +
+// upload / read-back), minus the canvas/render/Worker plumbing.  No CPU fallback: every entry
+// point needs a live HIP device and fails loudly otherwise.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "sb_engine.h"
+
+static thread_local std::string g_create_error;
+
+#define SB_FAIL(e, code, ...)                                   \
+    do {                                                        \
+        char _buf[512];                                         \
+        snprintf(_buf, sizeof _buf, __VA_ARGS__);               \
+        if (e) (e)->err = _buf; else g_create_error = _buf;     \
+        return (code);                                          \
+    } while (0)
+
+#define SB_HIP(e, call)                                                                       \
+    do {                                                                                      \
+        hipError_t _r = (call);                                                               \
+        if (_r != hipSuccess)                                                                 \
+            SB_FAIL(e, _r == hipErrorOutOfMemory ? SB_ERR_OOM : SB_ERR_HIP, "%s failed: %s",  \
+                    #call, hipGetErrorString(_r));                                            \
+    } while (0)
+
+template <typename T>
+static sb_status dev_alloc(sb_engine *e, T **p, size_t n)
+{
+    *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    void *q = nullptr;
+    SB_HIP(e, hipMalloc(&q, bytes));
+    e->allocs.push_back(q);
+    e->device_bytes += bytes;
+    *p = (T *)q;
+    return SB_OK;
+}
+
+#define SB_TRY(x)                          \
+    do {                                   \
+        sb_status _s = (x);                \
+        if (_s != SB_OK) return _s;        \
+    } while (0)
+
+static void free_scene(sb_engine *e)
+{
+    for (void *p : e->allocs) (void)hipFree(p);
+    e->allocs.clear();
+    e->device_bytes = 0;
+    e->loaded = false;
+    e->has_ghosts = false;
+    e->n_ghost = e->n_send = 0;
+}
+
+static inline uint32_t beam_stride(const sb_engine *e)
+{
+    return e->opt.layout == SB_LAYOUT_V1 ? SB_BEAM_STRIDE_V1 : SB_BEAM_STRIDE_V2;
+}
+static inline uint32_t map_isz(const sb_engine *e) { return e->opt.layout == SB_LAYOUT_V1 ? 2 : 4; }
+static inline uint32_t map_get(const sb_engine *e, const uint8_t *m, size_t id)
+{
+    if (e->opt.layout == SB_LAYOUT_V1) {
+        uint16_t v;
+        memcpy(&v, m + 2 * id, 2);
+        return v;
+    }
+    uint32_t v;
+    memcpy(&v, m + 4 * id, 4);
+    return v;
+}
+static inline void map_set(const sb_engine *e, uint8_t *m, size_t id, uint32_t val)
+{
+    if (e->opt.layout == SB_LAYOUT_V1) {
+        uint16_t v = (uint16_t)val;
+        memcpy(m + 2 * id, &v, 2);
+    } else {
+        memcpy(m + 4 * id, &val, 4);
+    }
+}
+static inline uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+extern "C" {
+
+uint32_t sb_abi_version(void) { return SB_ABI_VERSION; }
+
+const char *sb_last_error(const sb_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+void sb_default_options(sb_options *o)
+{
+    memset(o, 0, sizeof *o);
+    o->struct_size = sizeof *o;
+    o->bounds_size = 1000.0f;   // engineWorker.ts:39
+    o->particle_radius = 10.0f; // engineWorker.ts:40
+    o->subticks = 64;           // engineWorker.ts:41
+    o->max_particles = 65536;   // engineMapping.ts:362
+    o->max_beams = 65536;       // engineMapping.ts:363
+    o->layout = SB_LAYOUT_V1;
+    o->collision_mode = SB_COLLIDE_ALLPAIRS;
+    o->path = SB_PATH_AUTO;
+    o->device_ordinal = 0;
+}
+
+sb_status sb_create(const sb_options *opts, sb_engine **out)
+{
+    sb_engine *none = nullptr;
+    if (!opts || !out) SB_FAIL(none, SB_ERR_INVALID, "sb_create: null argument");
+    *out = nullptr;
+    if (opts->struct_size != sizeof(sb_options))
+        SB_FAIL(none, SB_ERR_INVALID, "sb_create: sb_options.struct_size %u != %zu", opts->struct_size, sizeof(sb_options));
+    if (opts->layout != SB_LAYOUT_V1 && opts->layout != SB_LAYOUT_V2)
+        SB_FAIL(none, SB_ERR_INVALID, "sb_create: unknown layout %u", opts->layout);
+    if (opts->layout == SB_LAYOUT_V1 && (opts->max_particles > 65536 || opts->max_beams > 65536))
+        SB_FAIL(none, SB_ERR_INVALID, "sb_create: v1 layout holds at most 65536 particles/beams (u16 indices)");
+    if (opts->max_particles == 0) SB_FAIL(none, SB_ERR_INVALID, "sb_create: max_particles is 0");
+    if (opts->collision_mode > SB_COLLIDE_GRID) SB_FAIL(none, SB_ERR_INVALID, "sb_create: unknown collision_mode");
+    if (opts->path > SB_PATH_TILED) SB_FAIL(none, SB_ERR_INVALID, "sb_create: unknown path");
+    if (!(opts->particle_radius > 0.f) || !(opts->bounds_size > 0.f) || opts->subticks == 0)
+        SB_FAIL(none, SB_ERR_INVALID, "sb_create: radius, bounds and subticks must be positive");
+    int ndev = 0;
+    hipError_t r = hipGetDeviceCount(&ndev);
+    if (r != hipSuccess || ndev <= 0)
+        SB_FAIL(none, SB_ERR_NO_DEVICE, "no HIP device available (%s); this engine has no CPU fallback",
+                r == hipSuccess ? "device count 0" : hipGetErrorString(r));
+    if (opts->device_ordinal < 0 || opts->device_ordinal >= ndev)
+        SB_FAIL(none, SB_ERR_NO_DEVICE, "device_ordinal %d out of range (%d devices)", opts->device_ordinal, ndev);
+    sb_engine *e = new sb_engine();
+    e->opt = *opts;
+    e->device = opts->device_ordinal;
+    e->subticks = (opts->subticks + 1) / 2 * 2; // engineWorker.ts:90
+    e->prm.bounds_size = opts->bounds_size;
+    e->prm.particle_radius = opts->particle_radius;
+    e->prm.time_step = 1.0f / (float)e->subticks; // engineWorker.ts:331
+    // the all-pairs scan sums contacts in ascending slot order (compute.wgsl:144); only the
+    // atomic path keeps particles in slot order, so it serves that mode
+    e->path = opts->path != SB_PATH_AUTO ? opts->path
+              : (opts->collision_mode == SB_COLLIDE_ALLPAIRS ? SB_PATH_ATOMIC : SB_PATH_TILED);
+    if (e->path == SB_PATH_TILED && opts->collision_mode == SB_COLLIDE_ALLPAIRS) {
+        g_create_error = "SB_PATH_TILED does not implement SB_COLLIDE_ALLPAIRS (use SB_COLLIDE_GRID, same bits, or SB_PATH_ATOMIC)";
+        delete e;
+        return SB_ERR_UNSUPPORTED;
+    }
+    if ((r = hipSetDevice(e->device)) != hipSuccess || (r = hipStreamCreate(&e->stream)) != hipSuccess ||
+        (r = hipEventCreate(&e->ev0)) != hipSuccess || (r = hipEventCreate(&e->ev1)) != hipSuccess) {
+        g_create_error = std::string("HIP init failed: ") + hipGetErrorString(r);
+        delete e;
+        return SB_ERR_HIP;
+    }
+    *out = e;
+    return SB_OK;
+}
+
+sb_status sb_destroy(sb_engine *e)
+{
+    if (!e) return SB_ERR_INVALID;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    free_scene(e);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return SB_OK;
+}
+
+sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_bytes, const void *mapping,
+                           size_t mapping_bytes, const void *particles, size_t particles_bytes,
+                           const void *beams, size_t beams_bytes)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!metadata || !mapping || !particles || (!beams && e->opt.max_beams))
+        SB_FAIL(e, SB_ERR_INVALID, "sb_write_buffers: null buffer");
+    const uint32_t maxP = e->opt.max_particles, maxB = e->opt.max_beams;
+    const uint32_t bstride = beam_stride(e);
+    if (metadata_bytes < SB_METADATA_BYTES) SB_FAIL(e, SB_ERR_INVALID, "metadata buffer is %zu bytes, need 112", metadata_bytes);
+    if (mapping_bytes < (size_t)(maxP + (size_t)maxB) * map_isz(e))
+        SB_FAIL(e, SB_ERR_INVALID, "mapping buffer is %zu bytes, need %zu", mapping_bytes, (size_t)(maxP + (size_t)maxB) * map_isz(e));
+    if (particles_bytes < (size_t)maxP * SB_PARTICLE_STRIDE)
+        SB_FAIL(e, SB_ERR_INVALID, "particle buffer is %zu bytes, need %zu", particles_bytes, (size_t)maxP * SB_PARTICLE_STRIDE);
+    if (beams_bytes < (size_t)maxB * bstride)
+        SB_FAIL(e, SB_ERR_INVALID, "beam buffer is %zu bytes, need %zu", beams_bytes, (size_t)maxB * bstride);
+    const uint8_t *md = (const uint8_t *)metadata, *mp = (const uint8_t *)mapping;
+    const uint8_t *pd = (const uint8_t *)particles, *bd = (const uint8_t *)beams;
+    const uint32_t P = rd_u32(md + 4), B = rd_u32(md + 24);
+    if (rd_u32(md + 40) != maxP || rd_u32(md + 44) != maxB)
+        SB_FAIL(e, SB_ERR_INVALID, "metadata max_particles/max_beams (%u/%u) differ from the engine capacity (%u/%u)",
+                rd_u32(md + 40), rd_u32(md + 44), maxP, maxB);
+    if (P > maxP || B > maxB) SB_FAIL(e, SB_ERR_INVALID, "metadata counts (%u/%u) exceed capacity (%u/%u)", P, B, maxP, maxB);
+
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    free_scene(e);
+
+    // ---- host shadows (copy semantics)
+    e->h_metadata.assign(md, md + SB_METADATA_BYTES);
+    e->h_mapping.assign(mp, mp + (size_t)(maxP + (size_t)maxB) * map_isz(e));
+    e->P = P;
+    e->B = B;
+    e->cur = 0;
+    e->substeps_done = 0;
+
+    // ---- particles: slot -> data index, must be a partial injection
+    std::vector<uint32_t> slot_index(P), internal_of_index(maxP, 0xFFFFFFFFu);
+    for (uint32_t s = 0; s < P; s++) {
+        uint32_t idx = map_get(e, mp, s);
+        if (idx >= maxP) SB_FAIL(e, SB_ERR_INVALID, "particle slot %u maps to data index %u >= max_particles", s, idx);
+        if (internal_of_index[idx] != 0xFFFFFFFFu)
+            SB_FAIL(e, SB_ERR_INVALID, "particle data index %u is mapped by two slots (%u and %u)", idx, internal_of_index[idx], s);
+        internal_of_index[idx] = s; // provisional: slot
+        slot_index[s] = idx;
+    }
+    // ---- beams: slot -> record; endpoints must be active particles
+    std::vector<SbHostBeam> hb(B);
+    {
+        std::vector<uint8_t> seen((size_t)maxB, 0);
+        for (uint32_t s = 0; s < B; s++) {
+            uint32_t idx = map_get(e, mp, (size_t)maxP + s);
+            if (idx >= maxB) SB_FAIL(e, SB_ERR_INVALID, "beam slot %u maps to data index %u >= max_beams", s, idx);
+            if (seen[idx]) SB_FAIL(e, SB_ERR_INVALID, "beam data index %u is mapped by two slots", idx);
+            seen[idx] = 1;
+            const uint8_t *rec = bd + (size_t)idx * bstride;
+            uint32_t a, b;
+            const uint8_t *f;
+            if (e->opt.layout == SB_LAYOUT_V1) { // engineMapping.ts:183-186, compute.wgsl:99-100
+                uint32_t pair = rd_u32(rec);
+                a = pair & 0xffffu;
+                b = pair >> 16;
+                f = rec + 4;
+            } else {
+                a = rd_u32(rec);
+                b = rd_u32(rec + 4);
+                f = rec + 8;
+            }
+            if (a >= maxP || b >= maxP || internal_of_index[a] == 0xFFFFFFFFu || internal_of_index[b] == 0xFFFFFFFFu)
+                SB_FAIL(e, SB_ERR_INVALID,
+                        "beam slot %u (data index %u) references particle data index %u/%u that no particle slot maps to",
+                        s, idx, a, b);
+            SbHostBeam &h = hb[s];
+            h.a = internal_of_index[a]; // slot of endpoint A (re-indexed below)
+            h.b = internal_of_index[b];
+            h.da = a;
+            h.db = b;
+            memcpy(h.f, f, 9 * sizeof(float));
+        }
+    }
+
+    // ---- internal particle order
+    std::vector<float> px(P), py(P);
+    for (uint32_t s = 0; s < P; s++) {
+        memcpy(&px[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE, 4);
+        memcpy(&py[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE + 4, 4);
+    }
+    SbTiling tl;
+    std::vector<uint32_t> order; // internal -> slot
+    if (e->path == SB_PATH_TILED) {
+        uint32_t target = e->opt.tile_particles ? e->opt.tile_particles : 1024;
+        sb_build_tiling(tl, px, py, hb, target);
+        order = tl.order;
+    } else {
+        order.resize(P);
+        std::iota(order.begin(), order.end(), 0u);
+    }
+    std::vector<uint32_t> internal_of_slot(P);
+    for (uint32_t i = 0; i < P; i++) internal_of_slot[order[i]] = i;
+    e->h_pslot = order;
+    e->h_pidx.resize(P);
+    for (uint32_t i = 0; i < P; i++) e->h_pidx[i] = slot_index[order[i]];
+
+    // ---- upload particles (A = data, B = zero: engineWorker.ts:588,593)
+    {
+        std::vector<float2> hp(P), hv(P), ha(P);
+        for (uint32_t i = 0; i < P; i++) {
+            float q[6];
+            memcpy(q, pd + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, SB_PARTICLE_STRIDE);
+            hp[i] = make_float2(q[0], q[1]);
+            hv[i] = make_float2(q[2], q[3]);
+            ha[i] = make_float2(q[4], q[5]);
+        }
+        for (int k = 0; k < 2; k++) {
+            SB_TRY(dev_alloc(e, &e->part[k].pos, P));
+            SB_TRY(dev_alloc(e, &e->part[k].vel, P));
+            SB_TRY(dev_alloc(e, &e->part[k].acc, P));
+        }
+        SB_HIP(e, hipMemcpy(e->part[0].pos, hp.data(), P * sizeof(float2), hipMemcpyHostToDevice));
+        SB_HIP(e, hipMemcpy(e->part[0].vel, hv.data(), P * sizeof(float2), hipMemcpyHostToDevice));
+        SB_HIP(e, hipMemcpy(e->part[0].acc, ha.data(), P * sizeof(float2), hipMemcpyHostToDevice));
+        SB_HIP(e, hipMemset(e->part[1].pos, 0, std::max<size_t>(P, 1) * sizeof(float2)));
+        SB_HIP(e, hipMemset(e->part[1].vel, 0, std::max<size_t>(P, 1) * sizeof(float2)));
+        SB_HIP(e, hipMemset(e->part[1].acc, 0, std::max<size_t>(P, 1) * sizeof(float2)));
+        SB_TRY(dev_alloc(e, &e->d_pidx, P));
+        SB_TRY(dev_alloc(e, &e->d_pslot, P));
+        SB_HIP(e, hipMemcpy(e->d_pidx, e->h_pidx.data(), P * 4, hipMemcpyHostToDevice));
+        SB_HIP(e, hipMemcpy(e->d_pslot, e->h_pslot.data(), P * 4, hipMemcpyHostToDevice));
+        SB_TRY(dev_alloc(e, &e->d_ghost, P));
+        SB_HIP(e, hipMemset(e->d_ghost, 0, std::max<size_t>(P, 1)));
+    }
+
+    // ---- beam copies
+    std::vector<uint32_t> c_ia, c_ib, c_pair, c_slot;
+    e->h_copy_of_slot.assign(B, 0);
+    if (e->path == SB_PATH_TILED) {
+        e->ntiles = tl.ntiles;
+        e->nhalo = (uint32_t)tl.halo_idx.size();
+        c_pair = tl.copy_pair;
+        c_slot = tl.copy_slot;
+        e->h_copy_of_slot = tl.copy_of_slot;
+        e->tile_cap_own = tl.max_own;
+        e->tile_cap_all = tl.max_all;
+        SB_TRY(dev_alloc(e, &e->d_tile_p0, tl.tile_p0.size()));
+        SB_TRY(dev_alloc(e, &e->d_tile_b0, tl.tile_b0.size()));
+        SB_TRY(dev_alloc(e, &e->d_tile_h0, tl.tile_h0.size()));
+        SB_TRY(dev_alloc(e, &e->d_halo_idx, tl.halo_idx.size()));
+        SB_HIP(e, hipMemcpy(e->d_tile_p0, tl.tile_p0.data(), tl.tile_p0.size() * 4, hipMemcpyHostToDevice));
+        SB_HIP(e, hipMemcpy(e->d_tile_b0, tl.tile_b0.data(), tl.tile_b0.size() * 4, hipMemcpyHostToDevice));
+        SB_HIP(e, hipMemcpy(e->d_tile_h0, tl.tile_h0.data(), tl.tile_h0.size() * 4, hipMemcpyHostToDevice));
+        if (!tl.halo_idx.empty())
+            SB_HIP(e, hipMemcpy(e->d_halo_idx, tl.halo_idx.data(), tl.halo_idx.size() * 4, hipMemcpyHostToDevice));
+        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_own * sizeof(int2);
+        if (tl.max_all > 65535)
+            SB_FAIL(e, SB_ERR_UNSUPPORTED, "a tile addresses %u particles (> 65535, 16-bit local indices): lower tile_particles", tl.max_all);
+        if (e->lds_bytes > 160 * 1024)
+            SB_FAIL(e, SB_ERR_UNSUPPORTED, "tile needs %zu bytes of LDS (> 160 KiB): lower tile_particles or use SB_PATH_ATOMIC", e->lds_bytes);
+    } else {
+        c_ia.resize(B);
+        c_ib.resize(B);
+        c_slot.resize(B);
+        for (uint32_t s = 0; s < B; s++) {
+            c_ia[s] = internal_of_slot[hb[s].a];
+            c_ib[s] = internal_of_slot[hb[s].b];
+            c_slot[s] = s;
+            e->h_copy_of_slot[s] = s;
+        }
+    }
+    const uint32_t nc = (uint32_t)c_slot.size();
+    e->nbeam = nc;
+    {
+        float *SbBeamArrays::*fields[9] = {&SbBeamArrays::length, &SbBeamArrays::target, &SbBeamArrays::last,
+                                           &SbBeamArrays::spring, &SbBeamArrays::damp,   &SbBeamArrays::yield,
+                                           &SbBeamArrays::limit,  &SbBeamArrays::strain, &SbBeamArrays::stress};
+        std::vector<float> tmp(nc);
+        for (int k = 0; k < 9; k++) {
+            for (uint32_t c = 0; c < nc; c++) tmp[c] = c_slot[c] == 0xFFFFFFFFu ? 0.0f : hb[c_slot[c]].f[k];
+            SB_TRY(dev_alloc(e, &(e->beams.*fields[k]), nc));
+            if (nc) SB_HIP(e, hipMemcpy(e->beams.*fields[k], tmp.data(), nc * 4, hipMemcpyHostToDevice));
+        }
+        SB_TRY(dev_alloc(e, &e->beams.slot, nc));
+        if (nc) SB_HIP(e, hipMemcpy(e->beams.slot, c_slot.data(), nc * 4, hipMemcpyHostToDevice));
+        if (e->path == SB_PATH_TILED) {
+            SB_TRY(dev_alloc(e, &e->beams.pair, nc));
+            if (nc) SB_HIP(e, hipMemcpy(e->beams.pair, c_pair.data(), nc * 4, hipMemcpyHostToDevice));
+        } else {
+            SB_TRY(dev_alloc(e, &e->beams.ia, nc));
+            SB_TRY(dev_alloc(e, &e->beams.ib, nc));
+            if (nc) SB_HIP(e, hipMemcpy(e->beams.ia, c_ia.data(), nc * 4, hipMemcpyHostToDevice));
+            if (nc) SB_HIP(e, hipMemcpy(e->beams.ib, c_ib.data(), nc * 4, hipMemcpyHostToDevice));
+        }
+    }
+    // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
+    SB_TRY(dev_alloc(e, &e->d_forces, P));
+    SB_HIP(e, hipMemset(e->d_forces, 0, std::max<size_t>(P, 1) * sizeof(int2)));
+    SB_TRY(dev_alloc(e, &e->d_broken, (nc + 31) / 32));
+    SB_HIP(e, hipMemset(e->d_broken, 0, std::max<size_t>((nc + 31) / 32, 1) * 4));
+    SB_TRY(dev_alloc(e, &e->d_dead_gen, B));
+    SB_HIP(e, hipMemset(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4));
+    e->delete_gen = 0;
+    SB_TRY(dev_alloc(e, &e->d_consts, 1));
+    SB_HIP(e, hipMemcpy(e->d_consts, md + 48, sizeof(SbConsts), hipMemcpyHostToDevice));
+    SB_HIP(e, hipDeviceSynchronize());
+    e->h_beams.swap(hb);
+    e->loaded = true;
+    return SB_OK;
+}
+
+sb_status sb_write_user_input(sb_engine *e, const void *bytes32)
+{
+    if (!e || !bytes32) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_write_user_input before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    memcpy(e->h_metadata.data() + SB_USER_INPUT_OFFSET, bytes32, SB_USER_INPUT_BYTES);
+    // pageable source: the copy is staged before the call returns, so no pointer is retained
+    SB_HIP(e, hipMemcpyAsync((uint8_t *)e->d_consts + 32, e->h_metadata.data() + SB_USER_INPUT_OFFSET,
+                             SB_USER_INPUT_BYTES, hipMemcpyHostToDevice, e->stream));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    return SB_OK;
+}
+
+sb_status sb_set_physics_constants(sb_engine *e, const float c8[8])
+{
+    if (!e || !c8) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_set_physics_constants before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    memcpy(e->h_metadata.data() + 48, c8, 32);
+    SB_HIP(e, hipMemcpyAsync(e->d_consts, e->h_metadata.data() + 48, 32, hipMemcpyHostToDevice, e->stream));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    return SB_OK;
+}
+
+sb_status sb_get_physics_constants(sb_engine *e, float c8[8])
+{
+    if (!e || !c8) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_get_physics_constants before sb_write_buffers");
+    memcpy(c8, e->h_metadata.data() + 48, 32);
+    return SB_OK;
+}
+
+sb_status sb_step(sb_engine *e, uint32_t n)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e);
+    SB_HIP(e, hipGetLastError());
+    return SB_OK;
+}
+
+sb_status sb_delete_pass(sb_engine *e)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_delete_pass before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    sbk_launch_delete(e);
+    SB_HIP(e, hipGetLastError());
+    return SB_OK;
+}
+
+sb_status sb_frame(sb_engine *e)
+{
+    if (!e) return SB_ERR_INVALID;
+    SB_TRY(sb_step(e, e->subticks)); // engineWorker.ts:655-661
+    return sb_delete_pass(e);       // engineWorker.ts:663-664
+}
+
+sb_status sb_sync(sb_engine *e)
+{
+    if (!e) return SB_ERR_INVALID;
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    return SB_OK;
+}
+
+sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
+{
+    if (!e || !ms) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step_timed before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipEventRecord(e->ev0, e->stream));
+    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e);
+    SB_HIP(e, hipGetLastError());
+    SB_HIP(e, hipEventRecord(e->ev1, e->stream));
+    SB_HIP(e, hipEventSynchronize(e->ev1));
+    SB_HIP(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return SB_OK;
+}
+
+// per-slot delete generation -> host; returns the number of dead slots
+static sb_status fetch_dead(sb_engine *e, std::vector<uint32_t> &dead, uint32_t *ndead)
+{
+    dead.assign(e->B, 0);
+    if (e->B && e->delete_gen) SB_HIP(e, hipMemcpy(dead.data(), e->d_dead_gen, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    for (uint32_t g : dead) n += g != 0;
+    *ndead = n;
+    return SB_OK;
+}
+
+sb_status sb_get_counts(sb_engine *e, uint32_t *particles, uint32_t *beams)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_get_counts before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    std::vector<uint32_t> dead;
+    uint32_t nd = 0;
+    SB_TRY(fetch_dead(e, dead, &nd));
+    if (particles) *particles = e->P;
+    if (beams) *beams = e->B - nd;
+    return SB_OK;
+}
+
+sb_status sb_load_buffers(sb_engine *e, void *metadata, size_t metadata_bytes, void *mapping, size_t mapping_bytes,
+                          void *particles, size_t particles_bytes, void *beams, size_t beams_bytes)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_load_buffers before sb_write_buffers");
+    const uint32_t maxP = e->opt.max_particles, maxB = e->opt.max_beams, P = e->P, B = e->B;
+    const uint32_t bstride = beam_stride(e);
+    if (metadata && metadata_bytes < SB_METADATA_BYTES) SB_FAIL(e, SB_ERR_INVALID, "metadata buffer too small");
+    if (mapping && mapping_bytes < (size_t)(maxP + (size_t)maxB) * map_isz(e)) SB_FAIL(e, SB_ERR_INVALID, "mapping buffer too small");
+    if (particles && particles_bytes < (size_t)maxP * SB_PARTICLE_STRIDE) SB_FAIL(e, SB_ERR_INVALID, "particle buffer too small");
+    if (beams && beams_bytes < (size_t)maxB * bstride) SB_FAIL(e, SB_ERR_INVALID, "beam buffer too small");
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipStreamSynchronize(e->stream)); // engineWorker.ts:554
+
+    std::vector<uint32_t> dead;
+    uint32_t nd = 0;
+    SB_TRY(fetch_dead(e, dead, &nd));
+
+    if (metadata) {
+        memcpy(metadata, e->h_metadata.data(), SB_METADATA_BYTES);
+        uint32_t bc = B - nd;
+        memcpy((uint8_t *)metadata + 24, &bc, 4); // metadata.beam_i_c, compute.wgsl:238
+    }
+    if (mapping) {
+        // replay the per-frame stable in-place compactions of the beam slots, pass by pass
+        // (compute.wgsl:221-233 intent); slots past the live count keep stale values
+        uint8_t *m = (uint8_t *)mapping;
+        memcpy(m, e->h_mapping.data(), e->h_mapping.size());
+        if (nd) {
+            std::vector<uint32_t> gens;
+            for (uint32_t g : dead)
+                if (g) gens.push_back(g);
+            std::sort(gens.begin(), gens.end());
+            gens.erase(std::unique(gens.begin(), gens.end()), gens.end());
+            std::vector<uint32_t> orig(B);
+            std::iota(orig.begin(), orig.end(), 0u);
+            uint32_t count = B;
+            for (uint32_t g : gens) {
+                uint32_t w = 0;
+                for (uint32_t s = 0; s < count; s++)
+                    if (dead[orig[s]] != g) {
+                        if (w != s) {
+                            map_set(e, m, (size_t)maxP + w, map_get(e, m, (size_t)maxP + s));
+                            orig[w] = orig[s];
+                        }
+                        w++;
+                    }
+                count = w;
+            }
+        }
+    }
+    if (particles && P) {
+        std::vector<float2> hp(P), hv(P), ha(P);
+        const SbParticleArrays &c = e->part[e->cur];
+        SB_HIP(e, hipMemcpy(hp.data(), c.pos, P * sizeof(float2), hipMemcpyDeviceToHost));
+        SB_HIP(e, hipMemcpy(hv.data(), c.vel, P * sizeof(float2), hipMemcpyDeviceToHost));
+        SB_HIP(e, hipMemcpy(ha.data(), c.acc, P * sizeof(float2), hipMemcpyDeviceToHost));
+        uint8_t *out = (uint8_t *)particles;
+        for (uint32_t i = 0; i < P; i++) {
+            float q[6] = {hp[i].x, hp[i].y, hv[i].x, hv[i].y, ha[i].x, ha[i].y};
+            memcpy(out + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, q, SB_PARTICLE_STRIDE);
+        }
+    }
+    if (beams && B) {
+        const uint32_t nc = e->nbeam;
+        std::vector<float> t(nc), l(nc), sn(nc), ss(nc);
+        SB_HIP(e, hipMemcpy(t.data(), e->beams.target, nc * 4, hipMemcpyDeviceToHost));
+        SB_HIP(e, hipMemcpy(l.data(), e->beams.last, nc * 4, hipMemcpyDeviceToHost));
+        SB_HIP(e, hipMemcpy(sn.data(), e->beams.strain, nc * 4, hipMemcpyDeviceToHost));
+        SB_HIP(e, hipMemcpy(ss.data(), e->beams.stress, nc * 4, hipMemcpyDeviceToHost));
+        uint8_t *out = (uint8_t *)beams;
+        const size_t foff = e->opt.layout == SB_LAYOUT_V1 ? 4 : 8;
+        for (uint32_t s = 0; s < B; s++) {
+            // every slot that was active at upload is written, dead ones with their last state
+            uint32_t c = e->h_copy_of_slot[s];
+            uint32_t idx = map_get(e, e->h_mapping.data(), (size_t)maxP + s);
+            uint8_t *rec = out + (size_t)idx * bstride, *f = rec + foff;
+            const SbHostBeam &h = e->h_beams[s];
+            if (e->opt.layout == SB_LAYOUT_V1) {
+                uint32_t pair = (h.da & 0xffffu) | (h.db << 16);
+                memcpy(rec, &pair, 4);
+            } else {
+                memcpy(rec, &h.da, 4);
+                memcpy(rec + 4, &h.db, 4);
+            }
+            memcpy(f, h.f, 9 * sizeof(float));
+            memcpy(f + 4, &t[c], 4);   // target_length
+            memcpy(f + 8, &l[c], 4);   // last_length
+            memcpy(f + 28, &sn[c], 4); // strain
+            memcpy(f + 32, &ss[c], 4); // stress
+        }
+    }
+    return SB_OK;
+}
+
+sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
+{
+    if (!e || !key || !value) return SB_ERR_INVALID;
+    std::string k(key);
+    if (k == "path") *value = e->path;
+    else if (k == "tiles") *value = e->ntiles;
+    else if (k == "beam_copies") *value = e->nbeam;
+    else if (k == "halo_particles") *value = e->nhalo;
+    else if (k == "device_bytes") *value = e->device_bytes;
+    else if (k == "substeps_done") *value = e->substeps_done;
+    else if (k == "lds_bytes") *value = e->lds_bytes;
+    else if (k == "kernels_per_substep")
+        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 3 : 0);
+    else SB_FAIL(e, SB_ERR_INVALID, "sb_get_info: unknown key '%s'", key);
+    return SB_OK;
+}
+
+sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_indices, uint32_t n_ghost,
+                            const uint32_t *send_indices, uint32_t n_send)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_configure before sb_write_buffers");
+    if ((n_ghost && !ghost_indices) || (n_send && !send_indices)) SB_FAIL(e, SB_ERR_INVALID, "null index list");
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    std::vector<uint32_t> internal_of_index(e->opt.max_particles, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < e->P; i++) internal_of_index[e->h_pidx[i]] = i;
+    auto translate = [&](const uint32_t *src, uint32_t n, std::vector<uint32_t> &dst) -> bool {
+        dst.resize(n);
+        for (uint32_t k = 0; k < n; k++) {
+            if (src[k] >= e->opt.max_particles || internal_of_index[src[k]] == 0xFFFFFFFFu) return false;
+            dst[k] = internal_of_index[src[k]];
+        }
+        return true;
+    };
+    std::vector<uint32_t> g, s;
+    if (!translate(ghost_indices, n_ghost, g) || !translate(send_indices, n_send, s))
+        SB_FAIL(e, SB_ERR_INVALID, "halo list names a particle data index that is not active");
+    std::vector<uint8_t> flags(e->P, 0);
+    for (uint32_t i : g) flags[i] = 1;
+    if (e->P) SB_HIP(e, hipMemcpy(e->d_ghost, flags.data(), e->P, hipMemcpyHostToDevice));
+    SB_TRY(dev_alloc(e, &e->d_ghost_list, n_ghost));
+    SB_TRY(dev_alloc(e, &e->d_send_list, n_send));
+    if (n_ghost) SB_HIP(e, hipMemcpy(e->d_ghost_list, g.data(), n_ghost * 4, hipMemcpyHostToDevice));
+    if (n_send) SB_HIP(e, hipMemcpy(e->d_send_list, s.data(), n_send * 4, hipMemcpyHostToDevice));
+    e->n_ghost = n_ghost;
+    e->n_send = n_send;
+    e->has_ghosts = n_ghost > 0;
+    return SB_OK;
+}
+
+sb_status sb_halo_pack(sb_engine *e, void *device_dst)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_pack before sb_write_buffers");
+    if (e->n_send && !device_dst) SB_FAIL(e, SB_ERR_INVALID, "null device buffer");
+    SB_HIP(e, hipSetDevice(e->device));
+    sbk_launch_halo_pack(e, (float4 *)device_dst);
+    SB_HIP(e, hipGetLastError());
+    return SB_OK;
+}
+
+sb_status sb_halo_unpack(sb_engine *e, const void *device_src)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_unpack before sb_write_buffers");
+    if (e->n_ghost && !device_src) SB_FAIL(e, SB_ERR_INVALID, "null device buffer");
+    SB_HIP(e, hipSetDevice(e->device));
+    sbk_launch_halo_unpack(e, (const float4 *)device_src);
+    SB_HIP(e, hipGetLastError());
+    return SB_OK;
+}
+
+sb_status sb_get_stream(sb_engine *e, void **hip_stream)
+{
+    if (!e || !hip_stream) return SB_ERR_INVALID;
+    *hip_stream = (void *)e->stream;
+    return SB_OK;
+}
+
+} // extern "C"

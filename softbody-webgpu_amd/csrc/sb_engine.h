@@ -1,0 +1,95 @@
+// sb_engine.h -- internal engine state behind the C ABI of include/softbody.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/softbody.h"
+#include "sb_physics.h"
+#include "sb_tiling.h"
+
+// Device SoA of the beam working set.  One entry per beam COPY: the atomic path keeps one
+// copy per active slot (slot order); the tiled path keeps per-tile slices in which a beam
+// cut by a tile boundary appears once in each of its two tiles (DESIGN.md "cut beams").
+struct SbBeamArrays {
+    uint32_t *ia, *ib;  // atomic path: internal particle indices of the endpoints
+    uint32_t *pair;     // tiled path: lo16 = tile-local index of A, hi16 = of B; 0xFFFFFFFF = dead
+    float *length, *target, *last, *spring, *damp, *yield, *limit, *strain, *stress;
+    uint32_t *slot;     // beam mapping slot (as of upload) this copy belongs to
+};
+
+struct SbParticleArrays {
+    float2 *pos, *vel, *acc;
+};
+
+struct sb_engine {
+    sb_options opt{};
+    SbParams prm{};
+    uint32_t subticks = 64;
+    uint32_t path = SB_PATH_ATOMIC;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    bool loaded = false;
+    uint32_t P = 0;        // active particles at upload
+    uint32_t B = 0;        // active beams at upload
+    uint32_t nbeam = 0;    // beam copies on the device
+    uint32_t cur = 0;      // which particle buffer holds the current state
+    uint64_t substeps_done = 0;
+
+    // host shadows (copy semantics: filled from the caller's buffers, never aliased)
+    std::vector<uint8_t> h_metadata; // 112 B
+    std::vector<uint8_t> h_mapping;  // full capacity, caller's layout
+    std::vector<uint32_t> h_pidx;    // internal particle -> data index
+    std::vector<uint32_t> h_pslot;   // internal particle -> mapping slot
+    std::vector<uint32_t> h_copy_of_slot; // beam slot -> index of the copy read back for it
+    std::vector<SbHostBeam> h_beams;      // static part of every active beam record, per slot
+
+    // device state
+    SbParticleArrays part[2]{};
+    SbBeamArrays beams{};
+    SbConsts *d_consts = nullptr;
+    uint32_t *d_pidx = nullptr;    // data index per internal particle (collision tie-break :153)
+    uint32_t *d_pslot = nullptr;
+    int2 *d_forces = nullptr;      // atomic path accumulator (compute.wgsl:68-69)
+    uint32_t *d_broken = nullptr;  // bit per beam copy: flagged this frame (compute.wgsl:86-88)
+    uint32_t *d_dead_gen = nullptr;  // per beam slot: number of the delete pass that removed it (0 = live)
+    uint32_t delete_gen = 0;
+    uint32_t *d_flags = nullptr;   // [0] = any beam flagged since the last delete pass
+    uint8_t *d_ghost = nullptr;    // per internal particle: 1 = owned by another rank
+    bool has_ghosts = false;
+    uint32_t *d_ghost_list = nullptr, *d_send_list = nullptr; // internal indices
+    uint32_t n_ghost = 0, n_send = 0;
+
+    // tiled path
+    uint32_t ntiles = 0, tile_cap_own = 0, tile_cap_all = 0;
+    uint32_t nhalo = 0;
+    uint32_t *d_tile_p0 = nullptr;    // [ntiles+1] first internal particle of each tile
+    uint32_t *d_tile_b0 = nullptr;    // [ntiles+1] first beam copy of each tile
+    uint32_t *d_tile_h0 = nullptr;    // [ntiles+1] first halo entry of each tile
+    uint32_t *d_halo_idx = nullptr;   // internal particle index of each halo entry
+    size_t lds_bytes = 0;
+
+    // spatial hash (SB_COLLIDE_GRID)
+    uint32_t grid_n = 0;
+    float grid_cell = 0.f;
+    uint32_t *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_of = nullptr;
+    uint32_t *d_sorted_id = nullptr; // internal particle index, sorted by cell
+    float4 *d_sorted_pv = nullptr;   // p,v of the sorted particles
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+
+    size_t device_bytes = 0;
+    std::vector<void *> allocs;
+};
+
+// sb_kernels.hip
+void sbk_launch_substep(sb_engine *e);
+void sbk_launch_delete(sb_engine *e);
+void sbk_launch_halo_pack(sb_engine *e, float4 *dst);
+void sbk_launch_halo_unpack(sb_engine *e, const float4 *src);
+size_t sbk_grid_scan_bytes(uint32_t ncell);

@@ -1,0 +1,282 @@
+// sb_kernels.hip -- HIP kernels of the substep for gfx950 (CDNA4, wave64).
+//
+// Two device schedules of the same canonical substep (S0 of SURVEY.md 8(a) A3: all beams
+// from the read state, then all particles):
+//   SB_PATH_ATOMIC  k_beams_atomic (global i32 atomics, compute.wgsl:127-130 as written)
+//                   + k_particles  (compute.wgsl:134-202)
+//   SB_PATH_TILED   k_substep_tiled: one workgroup per particle tile; beam forces are summed
+//                   with LDS integer atomics and consumed in the same launch.
+// Both are HBM-bandwidth-bound (no MFMA: < 1 flop/byte).
+#include "sb_engine.h"
+
+#define SB_BLOCK 256
+
+// ---------------------------------------------------------------- SB_PATH_ATOMIC
+
+__global__ __launch_bounds__(SB_BLOCK) void k_beams_atomic(SbBeamArrays b, uint32_t n,
+                                                           const float2 *__restrict__ pos,
+                                                           int2 *forces, uint32_t *broken)
+{
+    uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ia = b.ia[i];
+    if (ia == 0xFFFFFFFFu) return; // removed by a delete pass
+    uint32_t ib = b.ib[i];
+    SbBeamResult r = sb_beam_eval(pos[ia], pos[ib], b.length[i], b.target[i], b.last[i], b.spring[i],
+                                  b.damp[i], b.yield[i], b.limit[i]);
+    b.target[i] = r.target_length;
+    b.last[i] = r.last_length;
+    b.strain[i] = r.strain;
+    b.stress[i] = r.stress;
+    atomicAdd(&forces[ia].x, r.ax);
+    atomicAdd(&forces[ia].y, r.ay);
+    atomicAdd(&forces[ib].x, r.bx);
+    atomicAdd(&forces[ib].y, r.by);
+    if (r.broken) atomicOr(&broken[i >> 5], 1u << (i & 31));
+}
+
+// Collision loop over every other slot in ascending order (compute.wgsl:144-170), staged
+// through LDS 256 positions at a time.  Internal particle order == slot order on this path.
+template <int MODE>
+__global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbParticleArrays w,
+                                                        int2 *forces, uint32_t P,
+                                                        const SbConsts *__restrict__ cp, SbParams prm,
+                                                        const uint32_t *__restrict__ pidx,
+                                                        const uint8_t *__restrict__ ghost)
+{
+    __shared__ float2 s_pos[SB_BLOCK];
+    const SbConsts c = *cp;
+    uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    bool active = i < P;
+    SbParticle particle, self;
+    if (active) {
+        particle.p = r.pos[i];
+        particle.v = r.vel[i];
+        particle.a = r.acc[i];
+    } else {
+        particle.p = particle.v = particle.a = make_float2(0.f, 0.f);
+    }
+    self = particle;                                            // :141
+    const float elasticity_coeff = sb_div(c.elasticity + 1.0f, 2.0f); // :143
+    if (MODE == SB_COLLIDE_ALLPAIRS) {
+        const float two_r = prm.particle_radius * 2.0f;
+        for (uint32_t base = 0; base < P; base += SB_BLOCK) {
+            __syncthreads();
+            if (base + threadIdx.x < P) s_pos[threadIdx.x] = r.pos[base + threadIdx.x];
+            __syncthreads();
+            uint32_t cnt = min((uint32_t)SB_BLOCK, P - base);
+            if (active) {
+                for (uint32_t k = 0; k < cnt; k++) {
+                    uint32_t o = base + k;
+                    float2 op = s_pos[k];
+                    float dx = op.x - self.p.x, dy = op.y - self.p.y;
+                    float dist = sb_length(dx, dy);
+                    if (o != i && (dist == 0.0f || dist < two_r))
+                        sb_collide_pair(prm, c.friction, elasticity_coeff, particle, self, pidx[i], pidx[o],
+                                        op, r.vel[o]);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    int2 f = forces[i];
+    forces[i] = make_int2(0, 0); // atomicExchange(..., 0), :184-185
+    if (ghost && ghost[i]) return;
+    sb_particle_finish(prm, c, particle, f.x, f.y);
+    w.pos[i] = particle.p;
+    w.vel[i] = particle.v;
+    w.acc[i] = particle.a;
+}
+
+
+// ---------------------------------------------------------------- SB_PATH_TILED
+
+// Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md
+// "Workgroup dispatch"); tiles that are neighbours in the k-d order share halo particles, so
+// give each XCD a contiguous run of tiles and let its private L2 serve the shared lines.
+// Bijective for any n (speed only, never correctness).
+SB_DEV uint32_t sb_tile_of_block(uint32_t b, uint32_t n)
+{
+    uint32_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// One workgroup = one particle tile for one whole substep:
+//   phase 0  own + halo positions of the READ state -> LDS; LDS force accumulators = 0
+//   phase 1  stream the tile's beam slice (coalesced SoA), gather endpoints from LDS,
+//            evaluate compute.wgsl:103-130, ds_add the fixed-point force onto OWNED endpoints,
+//            write back target/last/strain/stress
+//   phase 2  consume the complete sums: compute.wgsl:171-201 per owned particle -> WRITE state
+// HBM traffic per substep = beam slice (36 B read + 16 B written per copy) + particles
+// (24 B read + 24 B written) + halo positions (8 B each, mostly L2 hits): the force
+// accumulator (compute.wgsl:68-69) never leaves the CU.
+template <int MODE>
+__global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
+    SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
+    const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
+    const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all,
+    const SbConsts *__restrict__ cp, SbParams prm, uint32_t *broken, const uint8_t *__restrict__ ghost)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
+    float2 *s_pos = (float2 *)sb_lds;
+    int *s_f = (int *)(s_pos + cap_all);
+
+    const uint32_t tile = sb_tile_of_block(blockIdx.x, ntiles);
+    const uint32_t p0 = tile_p0[tile], n_own = tile_p0[tile + 1] - p0;
+    const uint32_t h0 = tile_h0[tile], n_halo = tile_h0[tile + 1] - h0;
+    const uint32_t b0 = tile_b0[tile], nb = tile_b0[tile + 1] - b0;
+    const uint32_t tid = threadIdx.x;
+
+    for (uint32_t i = tid; i < n_own; i += SB_BLOCK) {
+        s_pos[i] = r.pos[p0 + i];
+        s_f[2 * i] = 0;
+        s_f[2 * i + 1] = 0;
+    }
+    for (uint32_t i = tid; i < n_halo; i += SB_BLOCK) s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
+    __syncthreads();
+
+#pragma unroll 2
+    for (uint32_t j = tid; j < nb; j += SB_BLOCK) {
+        const uint32_t c = b0 + j;
+        const uint32_t pair = b.pair[c];
+        if (pair == 0xFFFFFFFFu) continue; // padding or removed by a delete pass
+        const uint32_t la = pair & 0xffffu, lb = pair >> 16;
+        SbBeamResult res = sb_beam_eval(s_pos[la], s_pos[lb], b.length[c], b.target[c], b.last[c],
+                                        b.spring[c], b.damp[c], b.yield[c], b.limit[c]);
+        b.target[c] = res.target_length;
+        b.last[c] = res.last_length;
+        b.strain[c] = res.strain;
+        b.stress[c] = res.stress;
+        if (la < n_own) {
+            atomicAdd(&s_f[2 * la], res.ax);
+            atomicAdd(&s_f[2 * la + 1], res.ay);
+        }
+        if (lb < n_own) {
+            atomicAdd(&s_f[2 * lb], res.bx);
+            atomicAdd(&s_f[2 * lb + 1], res.by);
+        }
+        if (res.broken) atomicOr(&broken[c >> 5], 1u << (c & 31));
+    }
+    __syncthreads();
+
+    const SbConsts c = *cp;
+    for (uint32_t i = tid; i < n_own; i += SB_BLOCK) {
+        const uint32_t g = p0 + i;
+        if (ghost && ghost[g]) continue;
+        SbParticle particle;
+        particle.p = s_pos[i];
+        particle.v = r.vel[g];
+        particle.a = r.acc[g];
+        sb_particle_finish(prm, c, particle, s_f[2 * i], s_f[2 * i + 1]);
+        w.pos[g] = particle.p;
+        w.vel[g] = particle.v;
+        w.acc[g] = particle.a;
+    }
+}
+
+// ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
+
+// Canonical semantics: every copy of a beam flagged since the last pass stops
+// acting; its mapping slot records the number of the pass that removed it.  The host replays
+// the stable in-place compactions, pass by pass, when it reads the mapping back.
+__global__ __launch_bounds__(SB_BLOCK) void k_delete(SbBeamArrays b, uint32_t nwords, uint32_t nbeam,
+                                                     uint32_t *broken, uint32_t *dead_gen, uint32_t gen, int tiled)
+{
+    uint32_t w = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t bits = broken[w];
+    if (!bits) return;
+    broken[w] = 0;
+    while (bits) {
+        uint32_t k = __ffs(bits) - 1;
+        bits &= bits - 1;
+        uint32_t i = w * 32 + k;
+        if (i >= nbeam) break;
+        if (tiled) b.pair[i] = 0xFFFFFFFFu;
+        else b.ia[i] = 0xFFFFFFFFu;
+        dead_gen[b.slot[i]] = gen; // both copies of a cut beam store the same value
+    }
+}
+
+// ---------------------------------------------------------------- halo exchange helpers
+
+__global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(const float2 *__restrict__ pos,
+                                                        const float2 *__restrict__ vel,
+                                                        const uint32_t *__restrict__ list, uint32_t n,
+                                                        float4 *dst)
+{
+    uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    uint32_t i = list[k];
+    float2 p = pos[i], v = vel[i];
+    dst[k] = make_float4(p.x, p.y, v.x, v.y);
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(float2 *pos, float2 *vel,
+                                                          const uint32_t *__restrict__ list, uint32_t n,
+                                                          const float4 *__restrict__ src)
+{
+    uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    uint32_t i = list[k];
+    float4 s = src[k];
+    pos[i] = make_float2(s.x, s.y);
+    vel[i] = make_float2(s.z, s.w);
+}
+
+// ---------------------------------------------------------------- launchers
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+void sbk_launch_substep(sb_engine *e)
+{
+    SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
+    if (e->path == SB_PATH_ATOMIC) {
+        if (e->nbeam)
+            k_beams_atomic<<<cdiv(e->nbeam, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->beams, e->nbeam, r.pos,
+                                                                               e->d_forces, e->d_broken);
+        if (e->P) {
+            dim3 g(cdiv(e->P, SB_BLOCK));
+            const uint8_t *ghost = e->has_ghosts ? e->d_ghost : nullptr;
+            if (e->opt.collision_mode == SB_COLLIDE_ALLPAIRS)
+                k_particles<SB_COLLIDE_ALLPAIRS><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts,
+                                                                                e->prm, e->d_pidx, ghost);
+            else
+                k_particles<SB_COLLIDE_OFF><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts,
+                                                                           e->prm, e->d_pidx, ghost);
+        }
+    } else {
+        if (e->ntiles) {
+            const uint8_t *ghost = e->has_ghosts ? e->d_ghost : nullptr;
+            k_substep_tiled<SB_COLLIDE_OFF><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(
+                r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,
+                e->d_consts, e->prm, e->d_broken, ghost);
+        }
+    }
+    e->cur ^= 1;
+    e->substeps_done++;
+}
+
+void sbk_launch_delete(sb_engine *e)
+{
+    if (!e->nbeam) return;
+    uint32_t nwords = cdiv(e->nbeam, 32);
+    k_delete<<<cdiv(nwords, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->beams, nwords, e->nbeam, e->d_broken,
+                                                                 e->d_dead_gen, ++e->delete_gen, e->path == SB_PATH_TILED);
+}
+
+void sbk_launch_halo_pack(sb_engine *e, float4 *dst)
+{
+    if (!e->n_send) return;
+    SbParticleArrays c = e->part[e->cur];
+    k_halo_pack<<<cdiv(e->n_send, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(c.pos, c.vel, e->d_send_list, e->n_send, dst);
+}
+
+void sbk_launch_halo_unpack(sb_engine *e, const float4 *src)
+{
+    if (!e->n_ghost) return;
+    SbParticleArrays c = e->part[e->cur];
+    k_halo_unpack<<<cdiv(e->n_ghost, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(c.pos, c.vel, e->d_ghost_list, e->n_ghost, src);
+}
+
+size_t sbk_grid_scan_bytes(uint32_t) { return 0; }

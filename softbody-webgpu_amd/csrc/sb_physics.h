@@ -1,0 +1,245 @@
+// sb_physics.h -- device-side arithmetic of one substep (gfx950).
+//
+// Follows /root/reference/src/shaders/compute.wgsl line by line (cited per block) in the
+// canonical arithmetic DESIGN.md fixes: IEEE binary32, round-to-nearest-even, one rounding
+// per WGSL operator (build with -ffp-contract=off), correctly rounded sqrt and divide,
+// left-to-right evaluation as the WGSL source writes it.  Integer force accumulation
+// (compute.wgsl:68-71,127-130) is exact and order-free, which is what lets the tiled path
+// reduce forces in LDS without changing a bit of the result.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SB_DEV __device__ __forceinline__
+
+// metadata bytes 48..111 (compute.wgsl:42-53, engineMapping.ts:260-262), uploaded verbatim
+struct SbConsts {
+    float gravity_x, gravity_y;
+    float border_elasticity, border_friction, elasticity, friction, drag_coeff, drag_exp;
+    float user_strength;
+    uint32_t mouse_active;
+    float mouse_pos_x, mouse_pos_y, mouse_vel_x, mouse_vel_y, applied_force_x, applied_force_y;
+};
+static_assert(sizeof(SbConsts) == 64, "metadata tail is 64 bytes");
+
+// pipeline-overridable constants (compute.wgsl:1-3, engineWorker.ts:328-332)
+struct SbParams {
+    float bounds_size, particle_radius, time_step;
+};
+
+SB_DEV float sb_min(float a, float b) { return (b < a) ? b : a; }
+SB_DEV float sb_max(float a, float b) { return (a < b) ? b : a; }
+SB_DEV float sb_clamp(float x, float lo, float hi) { return sb_min(sb_max(x, lo), hi); }
+SB_DEV float sb_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+SB_DEV float sb_abs(float x) { return __uint_as_float(__float_as_uint(x) & 0x7fffffffu); }
+// Correctly rounded sqrt and divide.  On ROCm 7.2 `__fsqrt_rn` lowers to the bare 1-ulp
+// v_sqrt_f32; `__builtin_sqrtf` / operator `/` under -fhip-fp32-correctly-rounded-divide-sqrt
+// lower to the IEEE sequences (v_sqrt + residual fix-up; v_div_scale/fmas/fixup).  Checked in
+// the .s and by the bit-exact parity tests.
+SB_DEV float sb_sqrt(float x) { return __builtin_sqrtf(x); }
+SB_DEV float sb_div(float a, float b) { return a / b; }
+SB_DEV float sb_length(float x, float y) { return sb_sqrt(x * x + y * y); }
+
+// i32(f): truncate toward zero, saturating, NaN -> 0 (compute.wgsl:127-130)
+SB_DEV int32_t sb_f32_to_i32(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+
+// pow for the drag term (compute.wgsl:175).  Exact products for exponents 1..4, otherwise
+// exp2(y*log2 x) in binary64 from +,-,*,/ only (bit-reproducible on any IEEE machine).
+SB_DEV double sb_log2_d(double x)
+{
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff);
+    if (e == 0) {
+        x = x * 18014398509481984.0;
+        u = (uint64_t)__double_as_longlong(x);
+        e = (int)((u >> 52) & 0x7ff) - 54;
+    }
+    e -= 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double t = (m - 1.0) / (m + 1.0);
+    double t2 = t * t;
+    double s = 1.0 / 23.0;
+    s = s * t2 + 1.0 / 21.0;
+    s = s * t2 + 1.0 / 19.0;
+    s = s * t2 + 1.0 / 17.0;
+    s = s * t2 + 1.0 / 15.0;
+    s = s * t2 + 1.0 / 13.0;
+    s = s * t2 + 1.0 / 11.0;
+    s = s * t2 + 1.0 / 9.0;
+    s = s * t2 + 1.0 / 7.0;
+    s = s * t2 + 1.0 / 5.0;
+    s = s * t2 + 1.0 / 3.0;
+    s = s * t2 + 1.0;
+    double ln_m = 2.0 * t * s;
+    return (double)e + ln_m * 1.4426950408889634;
+}
+
+SB_DEV double sb_exp2_d(double x)
+{
+    if (x >= 1024.0) return __longlong_as_double(0x7ff0000000000000LL);
+    if (x <= -1100.0) return 0.0;
+    long long n = (long long)x;
+    if ((double)n > x) n -= 1;
+    double f = x - (double)n;
+    if (f > 0.5) { f = f - 1.0; n += 1; }
+    double z = f * 0.6931471805599453;
+    double s = 1.0 / 6227020800.0;
+    s = s * z + 1.0 / 479001600.0;
+    s = s * z + 1.0 / 39916800.0;
+    s = s * z + 1.0 / 3628800.0;
+    s = s * z + 1.0 / 362880.0;
+    s = s * z + 1.0 / 40320.0;
+    s = s * z + 1.0 / 5040.0;
+    s = s * z + 1.0 / 720.0;
+    s = s * z + 1.0 / 120.0;
+    s = s * z + 1.0 / 24.0;
+    s = s * z + 1.0 / 6.0;
+    s = s * z + 0.5;
+    s = s * z + 1.0;
+    s = s * z + 1.0;
+    long long n1 = n / 2, n2 = n - n1;
+    double p1 = __longlong_as_double((long long)((uint64_t)(n1 + 1023) << 52));
+    double p2 = __longlong_as_double((long long)((uint64_t)(n2 + 1023) << 52));
+    return s * p1 * p2;
+}
+
+SB_DEV float sb_pow(float x, float y)
+{
+    if (x != x || y != y) return x + y;
+    if (y == 1.0f) return x;
+    if (y == 2.0f) return x * x;
+    if (y == 3.0f) return x * x * x;
+    if (y == 4.0f) return (x * x) * (x * x);
+    const float inf = __uint_as_float(0x7f800000u);
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : inf);
+    if (x == inf) return (y > 0.0f) ? inf : ((y == 0.0f) ? 1.0f : 0.0f);
+    return (float)sb_exp2_d((double)y * sb_log2_d((double)x));
+}
+
+// ---------------------------------------------------------------- beam (compute.wgsl:103-130)
+
+struct SbBeamResult {
+    float target_length, last_length, strain, stress;
+    int32_t ax, ay, bx, by; // fixed-point contributions to endpoint A and endpoint B
+    bool broken;            // mark_beam_deleted condition (:117)
+};
+
+SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float target_length,
+                                 float last_length, float spring, float damp, float yield_strain,
+                                 float strain_break_limit)
+{
+    const float particle_force_scale = 65536.0f; // :70
+    const float beam_stress_scale = 1.0f / 20.0f; // :71
+    SbBeamResult r;
+    float dx = pb.x - pa.x, dy = pb.y - pa.y; // :103
+    if (sb_length(dx, dy) == 0.0f) {          // :104-107
+        dx = 0.0f;
+        dy = -1.0e-10f;
+    }
+    float len = sb_length(dx, dy);            // :108
+    float force_mag = (target_length - len) * spring + (last_length - len) * damp; // :110
+    float nx = sb_div(dx, len), ny = sb_div(dy, len); // normalize(diff)
+    float fx = force_mag * nx, fy = force_mag * ny;   // :111
+    float strain = sb_div(len - target_length, length); // :112
+    if (sb_abs(strain) > yield_strain)                  // :113-116
+        target_length = len - yield_strain * length * sb_sign(strain);
+    r.broken = sb_abs(len - length) > length * strain_break_limit; // :117
+    r.stress = force_mag * beam_stress_scale;                      // :122
+    r.strain = sb_div(sb_abs(strain), yield_strain);               // :123
+    r.last_length = len;                                           // :124
+    r.target_length = target_length;
+    r.ax = sb_f32_to_i32(-fx * particle_force_scale); // :127
+    r.ay = sb_f32_to_i32(-fy * particle_force_scale); // :128
+    r.bx = sb_f32_to_i32(fx * particle_force_scale);  // :129
+    r.by = sb_f32_to_i32(fy * particle_force_scale);  // :130
+    return r;
+}
+
+// ---------------------------------------------------------------- particle (compute.wgsl:139-201)
+
+struct SbParticle {
+    float2 p, v, a;
+};
+
+// one iteration of the collision loop, compute.wgsl:148-169.  `self` is const_particle (:141).
+SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticity_coeff,
+                            SbParticle &particle, const SbParticle &self, uint32_t index,
+                            uint32_t other_index, float2 op, float2 ov)
+{
+    float dx = op.x - self.p.x, dy = op.y - self.p.y;
+    float dist = sb_length(dx, dy); // :150
+    if (dist == 0.0f) {             // :151-154
+        particle.p.y += sb_sign((float)index - (float)other_index);
+    } else if (dist < prm.particle_radius * 2.0f) { // :155
+        float nx = sb_div(dx, dist), ny = sb_div(dy, dist);   // :156
+        float tx = -ny, ty = nx;                              // :157
+        float ux = self.v.x - ov.x, uy = self.v.y - ov.y;     // :158
+        float impulse_normal = elasticity_coeff * (ux * nx + uy * ny); // :159
+        float max_friction = impulse_normal * friction;               // :160
+        float impulse_tangent = sb_clamp(ux * tx + uy * ty, -max_friction, max_friction); // :161
+        particle.v.x -= impulse_normal * nx + impulse_tangent * tx;   // :162
+        particle.v.y -= impulse_normal * ny + impulse_tangent * ty;
+        float overlap = prm.particle_radius * 2.0f - dist;            // :164
+        float csx = sb_div(nx * overlap, 2.0f), csy = sb_div(ny * overlap, 2.0f);
+        float dt2 = prm.time_step * prm.time_step;                    // :168
+        particle.a.x -= sb_div(csx, dt2);
+        particle.a.y -= sb_div(csy, dt2);
+    }
+}
+
+// everything after the collision loop, compute.wgsl:171-199; fx,fy are the complete fixed-point
+// beam force sums for this particle (the atomicExchange results of :184-185).
+SB_DEV void sb_particle_finish(const SbParams &prm, const SbConsts &c, SbParticle &particle,
+                               int32_t fx, int32_t fy)
+{
+    const float particle_force_scale = 65536.0f;
+    particle.a.x += c.gravity_x; // :172
+    particle.a.y += c.gravity_y;
+    float vl = sb_length(particle.v.x, particle.v.y);
+    if (vl > 0.0f) { // :174-176
+        float nx = sb_div(particle.v.x, vl), ny = sb_div(particle.v.y, vl);
+        float px = sb_pow(sb_abs(particle.v.x), c.drag_exp);
+        float py = sb_pow(sb_abs(particle.v.y), c.drag_exp);
+        particle.a.x -= c.drag_coeff * px * nx;
+        particle.a.y -= c.drag_coeff * py * ny;
+    }
+    particle.a.x += c.applied_force_x * c.user_strength; // :178
+    particle.a.y += c.applied_force_y * c.user_strength;
+    if (c.mouse_active > 0u) { // :179-181
+        float mx = c.mouse_pos_x - particle.p.x, my = c.mouse_pos_y - particle.p.y;
+        if (sb_length(mx, my) < prm.particle_radius * 10.0f) {
+            particle.a.x += (c.mouse_vel_x - particle.v.x) * c.user_strength - c.gravity_x;
+            particle.a.y += (c.mouse_vel_y - particle.v.y) * c.user_strength - c.gravity_y;
+        }
+    }
+    particle.a.x += sb_div((float)fx, particle_force_scale); // :184-185
+    particle.a.y += sb_div((float)fy, particle_force_scale);
+    particle.v.x += particle.a.x * prm.time_step; // :186
+    particle.v.y += particle.a.y * prm.time_step;
+    particle.p.x += particle.v.x * prm.time_step; // :187
+    particle.p.y += particle.v.y * prm.time_step;
+    particle.a.x = 0.0f; // :188
+    particle.a.y = 0.0f;
+    float lo = prm.particle_radius, hi = prm.bounds_size - prm.particle_radius; // :190
+    float cx = sb_clamp(particle.p.x, lo, hi), cy = sb_clamp(particle.p.y, lo, hi);
+    if (particle.p.x != cx) { // :191-194
+        particle.a.y -= sb_min(particle.a.y, sb_sign(particle.v.y) * c.border_friction *
+                                                 sb_abs(particle.v.x) * (1.0f + c.border_elasticity));
+        particle.v.x *= -c.border_elasticity;
+    }
+    if (particle.p.y != cy) { // :195-198
+        particle.a.x -= sb_min(particle.a.x, sb_sign(particle.v.x) * c.border_friction *
+                                                 sb_abs(particle.v.y) * (1.0f + c.border_elasticity));
+        particle.v.y *= -c.border_elasticity;
+    }
+    particle.p.x = cx; // :199
+    particle.p.y = cy;
+}

@@ -1,0 +1,155 @@
+// sb_tiling.h -- host-side partition of a scene into particle tiles for SB_PATH_TILED.
+//
+// A tile is a spatially compact set of <= `target` particles (recursive coordinate bisection
+// of the uploaded positions) that one workgroup keeps in LDS for a whole substep.  Every beam
+// is stored in the slice of the tile that owns its endpoints; a beam whose endpoints live in
+// two tiles ("cut beam") is stored in BOTH slices, each with its own copy of the dynamic state
+// (target/last/strain/stress).  The two copies see identical inputs (read-buffer positions) and
+// run identical arithmetic, so they stay bit-identical forever; each tile applies only the force
+// on the endpoint it owns.  That is what removes every global atomic and every inter-workgroup
+// dependency from the substep (DESIGN.md "cut beams").
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+struct SbHostBeam {
+    uint32_t a, b;   // endpoints as particle mapping SLOTS
+    uint32_t da, db; // endpoints as particle DATA indices (what the caller's record holds)
+    float f[9];      // length, target, last, spring, damp, yield, limit, strain, stress
+};
+
+struct SbTiling {
+    uint32_t ntiles = 0;
+    std::vector<uint32_t> order;        // internal particle -> slot (tiles are contiguous ranges)
+    std::vector<uint32_t> tile_p0;      // [ntiles+1]
+    std::vector<uint32_t> tile_b0;      // [ntiles+1] beam-copy ranges (padded to x4 with dead copies)
+    std::vector<uint32_t> tile_h0;      // [ntiles+1] halo ranges
+    std::vector<uint32_t> halo_idx;     // internal particle index of each halo entry
+    std::vector<uint32_t> copy_pair;    // lo16 local A | hi16 local B; 0xFFFFFFFF = padding
+    std::vector<uint32_t> copy_slot;    // beam slot of each copy; 0xFFFFFFFF = padding
+    std::vector<uint32_t> copy_of_slot; // beam slot -> the copy in the tile that owns endpoint A
+    uint32_t max_own = 0, max_all = 0;
+    uint64_t cut_beams = 0;
+};
+
+namespace sbt {
+
+struct Splitter {
+    const std::vector<float> &x, &y;
+    std::vector<uint32_t> &order;
+    std::vector<uint32_t> &tile_p0;
+    uint32_t target;
+
+    static float key(float v) { return std::isfinite(v) ? v : 0.0f; }
+
+    void split(uint32_t lo, uint32_t hi, uint32_t k)
+    {
+        // [lo,hi) becomes k tiles of near-equal population
+        if (k <= 1) {
+            std::sort(order.begin() + lo, order.begin() + hi); // slot order inside a tile
+            tile_p0.push_back(hi);
+            return;
+        }
+        float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+        for (uint32_t i = lo; i < hi; i++) {
+            float vx = key(x[order[i]]), vy = key(y[order[i]]);
+            minx = std::min(minx, vx); maxx = std::max(maxx, vx);
+            miny = std::min(miny, vy); maxy = std::max(maxy, vy);
+        }
+        const bool along_x = (maxx - minx) >= (maxy - miny);
+        const std::vector<float> &c = along_x ? x : y;
+        uint32_t kl = k / 2;
+        uint32_t nl = (uint32_t)(((uint64_t)(hi - lo) * kl) / k);
+        auto cmp = [&](uint32_t p, uint32_t q) {
+            float a = key(c[p]), b = key(c[q]);
+            return a < b || (a == b && p < q);
+        };
+        std::nth_element(order.begin() + lo, order.begin() + lo + nl, order.begin() + hi, cmp);
+        split(lo, lo + nl, kl);
+        split(lo + nl, hi, k - kl);
+    }
+};
+
+} // namespace sbt
+
+// px,py: position per particle slot; beams: per beam slot, endpoints as particle slots.
+inline void sb_build_tiling(SbTiling &t, const std::vector<float> &px, const std::vector<float> &py,
+                            const std::vector<SbHostBeam> &beams, uint32_t target)
+{
+    const uint32_t P = (uint32_t)px.size(), B = (uint32_t)beams.size();
+    target = std::max(64u, std::min(target, 16384u));
+    t.order.resize(P);
+    for (uint32_t i = 0; i < P; i++) t.order[i] = i;
+    t.tile_p0.clear();
+    t.tile_p0.push_back(0);
+    if (P) {
+        uint32_t k = (P + target - 1) / target;
+        sbt::Splitter sp{px, py, t.order, t.tile_p0, target};
+        sp.split(0, P, k);
+    }
+    t.ntiles = (uint32_t)t.tile_p0.size() - 1;
+    std::vector<uint32_t> internal_of_slot(P), tile_of(P);
+    for (uint32_t i = 0; i < P; i++) internal_of_slot[t.order[i]] = i;
+    for (uint32_t k = 0; k < t.ntiles; k++)
+        for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = k;
+
+    // pass 1: count copies and collect halo candidates per tile
+    std::vector<uint32_t> ncopy(t.ntiles + 1, 0);
+    std::vector<std::vector<uint32_t>> halo(t.ntiles);
+    t.cut_beams = 0;
+    for (uint32_t s = 0; s < B; s++) {
+        uint32_t ia = internal_of_slot[beams[s].a], ib = internal_of_slot[beams[s].b];
+        uint32_t ta = tile_of[ia], tb = tile_of[ib];
+        ncopy[ta]++;
+        if (tb != ta) {
+            ncopy[tb]++;
+            halo[ta].push_back(ib);
+            halo[tb].push_back(ia);
+            t.cut_beams++;
+        }
+    }
+    t.tile_h0.assign(t.ntiles + 1, 0);
+    t.tile_b0.assign(t.ntiles + 1, 0);
+    t.max_own = t.max_all = 0;
+    for (uint32_t k = 0; k < t.ntiles; k++) {
+        auto &h = halo[k];
+        std::sort(h.begin(), h.end());
+        h.erase(std::unique(h.begin(), h.end()), h.end());
+        t.tile_h0[k + 1] = t.tile_h0[k] + (uint32_t)h.size();
+        t.tile_b0[k + 1] = t.tile_b0[k] + (ncopy[k] + 3) / 4 * 4;
+        uint32_t own = t.tile_p0[k + 1] - t.tile_p0[k];
+        t.max_own = std::max(t.max_own, own);
+        t.max_all = std::max(t.max_all, own + (uint32_t)h.size());
+    }
+    t.halo_idx.resize(t.tile_h0[t.ntiles]);
+    for (uint32_t k = 0; k < t.ntiles; k++) std::copy(halo[k].begin(), halo[k].end(), t.halo_idx.begin() + t.tile_h0[k]);
+
+    // pass 2: emit copies in slot order inside each tile
+    const uint32_t total = t.tile_b0[t.ntiles];
+    t.copy_pair.assign(total, 0xFFFFFFFFu);
+    t.copy_slot.assign(total, 0xFFFFFFFFu);
+    t.copy_of_slot.assign(B, 0);
+    std::vector<uint32_t> cursor(t.tile_b0.begin(), t.tile_b0.end() - 1);
+    auto local = [&](uint32_t tile, uint32_t internal) -> uint32_t {
+        if (tile_of[internal] == tile) return internal - t.tile_p0[tile];
+        const auto &h = halo[tile];
+        uint32_t pos = (uint32_t)(std::lower_bound(h.begin(), h.end(), internal) - h.begin());
+        return (t.tile_p0[tile + 1] - t.tile_p0[tile]) + pos;
+    };
+    for (uint32_t s = 0; s < B; s++) {
+        uint32_t ia = internal_of_slot[beams[s].a], ib = internal_of_slot[beams[s].b];
+        uint32_t ta = tile_of[ia], tb = tile_of[ib];
+        uint32_t c = cursor[ta]++;
+        t.copy_pair[c] = local(ta, ia) | (local(ta, ib) << 16);
+        t.copy_slot[c] = s;
+        t.copy_of_slot[s] = c;
+        if (tb != ta) {
+            uint32_t d = cursor[tb]++;
+            t.copy_pair[d] = local(tb, ia) | (local(tb, ib) << 16);
+            t.copy_slot[d] = s;
+        }
+    }
+}

@@ -1,0 +1,179 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (DESIGN.md "parity"): bit-exact.  The force accumulation is integer (order-free) and both
+sides run the same canonical IEEE arithmetic, so every particle and beam float must match
+bit for bit, for both device schedules (atomic / tiled).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOMIC, TILED = 1, 2
+OFF, ALLPAIRS, GRID = 0, 1, 2
+
+
+def run_both(sb, oracle, buf, *, n=None, frames=0, path=0, mode=ALLPAIRS, bounds=1000.0, radius=10.0,
+             subticks=64, tile=0, before=None, ref_mode=None):
+    eng = sb.Engine(bounds_size=bounds, particle_radius=radius, subticks=subticks, layout=buf.layout,
+                    max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
+                    path=path, tile_particles=tile)
+    ref = oracle.OracleEngine(bounds, radius, subticks, buf.layout, mode if ref_mode is None else ref_mode,
+                              threads=8)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    if before:
+        before(eng, ref)
+    for _ in range(frames):
+        eng.frame()
+        ref.frame()
+    if n:
+        eng.step(n)
+        ref.step(n)
+    got = eng.load_buffers(buf.copy())
+    exp = ref.load_buffers(buf.copy())
+    info = dict(path=eng.info("path"), tiles=eng.info("tiles"), copies=eng.info("beam_copies"))
+    eng.destroy()
+    return got, exp, info
+
+
+def assert_same(got, exp, what=""):
+    P, B = exp.particle_count, exp.beam_count
+    assert (got.particle_count, got.beam_count) == (P, B), what
+    assert np.array_equal(got.metadata, exp.metadata), what
+    assert np.array_equal(got.mapping, exp.mapping), what
+    gp, ep = got.particles.view("<u4"), exp.particles.view("<u4")
+    bad = np.nonzero((gp != ep).any(axis=1))[0]
+    assert bad.size == 0, "%s: %d particles differ, first %d: %s vs %s" % (
+        what, bad.size, bad[0], got.particles[bad[0]], exp.particles[bad[0]])
+    assert got.beams.tobytes() == exp.beams.tobytes(), what + ": beam state differs"
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_default_scene_frames_allpairs(sb, oracle, layout):
+    """The reference's own default scene (main.ts:188-246), 3 frames of 64 substeps with the
+    reference's all-pairs collisions; blobs fall, hit the floor and each other."""
+    buf = sb.scenes.default_buffers(layout, 256, 512)
+    got, exp, info = run_both(sb, oracle, buf, frames=3, mode=ALLPAIRS)
+    assert info["path"] == ATOMIC
+    assert_same(got, exp, "default scene v%d" % layout)
+    assert not np.array_equal(got.particles, buf.particles)
+
+
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_default_scene_no_collisions_both_paths(sb, oracle, path):
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    got, exp, info = run_both(sb, oracle, buf, frames=2, n=7, mode=OFF, path=path, tile=64)
+    assert info["path"] == path
+    if path == TILED:
+        assert info["tiles"] >= 2 and info["copies"] > 299   # cut beams are duplicated
+    assert_same(got, exp, "default scene path %d" % path)
+
+
+@pytest.mark.parametrize("path,tile", [(ATOMIC, 0), (TILED, 256), (TILED, 1024)])
+def test_lattice_parity_1000_substeps(sb, oracle, path, tile):
+    """BASELINE config 1 shape (32x32 lattice, 1000 substeps, dt=1/64) plus jitter so every beam
+    carries force; bit-exact after 1000 substeps on both schedules."""
+    buf = sb.scenes.lattice_buffers(32, 32, d=25.0, origin=(100.0, 100.0), spring=50.0, damp=700.0,
+                                    yield_strain=0.2, strain_limit=0.5, jitter=2.0, layout=2)
+    got, exp, info = run_both(sb, oracle, buf, n=1000, mode=OFF, path=path, tile=tile)
+    assert_same(got, exp, "lattice path %d tile %d" % (path, tile))
+
+
+def test_lattice_64k_tiled(sb, oracle):
+    """256x256 = 65 536 particles / 195 585 beams, 64 tiles, falling onto the floor (border
+    response active), 128 substeps."""
+    buf = sb.scenes.lattice_buffers(256, 256, d=30.0, origin=(40.0, 12.0), jitter=1.0, layout=2,
+                                    velocity=(0.5, -3.0))
+    got, exp, info = run_both(sb, oracle, buf, n=128, mode=OFF, path=TILED, bounds=8000.0)
+    assert info["tiles"] == 64
+    assert_same(got, exp, "64k lattice")
+    assert (got.particles[:, 1] == 10.0).any()  # some particles sit on the floor clamp
+
+
+def test_yield_break_and_delete(sb, oracle):
+    """Plastic yield, break flags and the per-frame delete pass (compute.wgsl:113-121, 205-246;
+    canonical stable compaction): a lattice thrown hard at the wall."""
+    buf = sb.scenes.lattice_buffers(12, 12, d=30.0, origin=(30.0, 30.0), spring=50.0, damp=100.0,
+                                    yield_strain=0.05, strain_limit=0.12, layout=1, velocity=(-40.0, -35.0),
+                                    slack=8)
+    for path, mode in ((ATOMIC, ALLPAIRS), (TILED, OFF), (ATOMIC, OFF)):
+        got, exp, info = run_both(sb, oracle, buf, frames=3, mode=mode, path=path, tile=64)
+        assert exp.beam_count < buf.beam_count, "scene must break beams"
+        assert_same(got, exp, "break path %d" % path)
+    assert (exp.beams["target_length"][:exp.beam_count] != exp.beams["length"][:exp.beam_count]).any()
+
+
+def test_user_input_and_constants(sb, oracle):
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    buf.user_strength = 1.5
+
+    def before(eng, ref):
+        b = buf.copy()
+        b.set_user_input(applied_force=(0.3, 0.1), mouse_pos=(200.0, 150.0), mouse_vel=(4.0, 2.0), mouse_active=True)
+        ui = b.user_input_bytes()
+        eng.write_user_input(ui)
+        ref.write_user_input(ui)
+        c = np.array([0.1, -0.8, 0.4, 0.3, 0.6, 0.2, 0.002, 2.5], "f4")  # drag_exp 2.5 -> general pow
+        eng.set_physics_constants(c)
+        ref.set_physics_constants(c)
+
+    got, exp, _ = run_both(sb, oracle, buf, frames=2, mode=ALLPAIRS, before=before)
+    assert_same(got, exp, "user input")
+    assert got.metadata.view("<f4")[19] == np.float32(2.5)
+
+
+def test_nonidentity_mapping(sb, oracle):
+    """Slots need not equal data indices (engineMapping.ts:336-339): permute both mappings."""
+    buf = sb.scenes.default_buffers(2, 256, 512)
+    rng = np.random.default_rng(3)
+    P, B = buf.particle_count, buf.beam_count
+    pp, bp = rng.permutation(P), rng.permutation(B)
+    # move particle i to data index pp[i] + 50, beam j to bp[j] + 100, slots shuffled
+    newp = np.zeros_like(buf.particles)
+    newp[pp + 50] = buf.particles[:P]
+    newb = np.zeros_like(buf.beams)
+    bb = buf.beams[:B].copy()
+    bb["a"] = pp[bb["a"]] + 50
+    bb["b"] = pp[bb["b"]] + 50
+    newb[bp + 100] = bb
+    buf.particles[:] = newp
+    buf.beams[:] = newb
+    buf.mapping[:P] = rng.permutation(pp + 50)
+    buf.mapping[buf.max_particles:buf.max_particles + B] = rng.permutation(bp + 100)
+    for path, mode in ((ATOMIC, ALLPAIRS), (TILED, OFF)):
+        got, exp, _ = run_both(sb, oracle, buf, frames=1, mode=mode, path=path, tile=64)
+        assert_same(got, exp, "permuted mapping path %d" % path)
+
+
+def test_odd_substep_count_and_restep(sb, oracle):
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    eng = sb.Engine(layout=1, max_particles=256, max_beams=512, collision_mode=OFF)
+    ref = oracle.OracleEngine(1000.0, 10.0, 64, 1, OFF)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    for n in (3, 5, 1):
+        eng.step(n)
+        ref.step(n)
+        got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+        P = exp.particle_count
+        assert np.array_equal(got.particles[:P].view("u4"), exp.particles[:P].view("u4"))
+    eng.destroy()
+
+
+def test_errors_are_loud(sb):
+    eng = sb.Engine(layout=1, max_particles=16, max_beams=16, collision_mode=OFF)
+    with pytest.raises(sb.engine.EngineError) as ei:
+        eng.step(1)
+    assert ei.value.status == 5
+    buf = sb.Buffers(1, 16, 16)
+    beams = np.zeros(1, sb.layout.BEAM_DTYPE[1])
+    beams[0]["a"], beams[0]["b"], beams[0]["length"] = 0, 9, 10.0   # endpoint 9 is not an active particle
+    buf.set_scene(np.zeros((2, 6), "f4"), beams)
+    with pytest.raises(sb.engine.EngineError) as ei:
+        eng.write_buffers(buf)
+    assert ei.value.status == 1 and "references particle" in str(ei.value)
+    wrong = sb.Buffers(1, 32, 16)
+    with pytest.raises(sb.engine.EngineError):
+        eng.write_buffers(wrong)
+    eng.destroy()
