@@ -71,6 +71,26 @@ def cpu_baseline(sb, buf, bounds, mode, budget_s):
     }
 
 
+def committed_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_summary.json, made by tools/gpu_profile.sh + tools/summarize_profiles.py from
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE x2 per the
+    gfx950 correction and our own calibration run).  None unless it was taken on this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            s = json.load(open(f))
+            if s.get("bench", {}).get("config", {}).get("workload") != workload:
+                continue
+            for name, t in s.get("traffic", {}).items():
+                if name.startswith(kernel):
+                    best = (t["hbm_bytes_per_launch"], os.path.basename(f))
+        except Exception:
+            continue
+    return best
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -141,6 +161,9 @@ def main():
         P_total = P_local
 
     if rank == 0:
+        workload = ("BASELINE config 2: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
+                    "spring 50 damp 700, jitter 1.0, subticks 64, collisions %s, v2 (u32) layout"
+                    % (W, H, P_local, B_local, a.collisions))
         copies = eng.info("beam_copies")
         alg_bytes = 52.0 * B_local + 48.0 * P_local  # per substep, one launch
         roof = None
@@ -154,14 +177,17 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "achieved = (52*B + 48*P) bytes / (HIP-event time of the timed region / steps); "
                             "beam copies on device: %d for %d beams" % (copies, B_local)}
+        if roof is not None:
+            tr = committed_traffic(workload, roof["kernel"])
+            if tr:
+                roof["traffic"] = tr[0]
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
         line = {
             "metric": "particle-steps/sec", "value": P_total * a.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
-                                   "spring 50 damp 700, jitter 1.0, subticks 64, collisions %s, v2 (u32) layout"
-                                   % (W, H, P_local, B_local, a.collisions),
+            "config": {"workload": workload,
                        "particles_total": P_total, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
                        "tiles": eng.info("tiles"),
                        "parallelism": "single GPU" if world == 1 else "%d x-slabs, ghost p,v exchange per substep over RCCL" % world},

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU tests, the default bench, rocprofv3 kernel trace + PMC passes.
+# Usage: tools/gpu_profile.sh <round-tag>
+set -o pipefail
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -3 $OUT/pytest_gpu.log
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo bench failed; tail -5 $OUT/bench.err; exit 1; }
+cat $OUT/bench.json | cut -c1-300
+BENCH="python3 $PWD/bench.py --steps 200 --warmup 16 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { echo pmc fetch failed; tail -5 $OUT/pmc_fetch.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || { echo pmc write failed; tail -5 $OUT/pmc_write.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- $OLDPWD/tools/hbm_calib > $OUT/calib_fetch.log 2>&1 || { echo calib fetch failed; tail -5 $OUT/calib_fetch.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calib_write -- $OLDPWD/tools/hbm_calib > $OUT/calib_write.log 2>&1 || { echo calib write failed; tail -5 $OUT/calib_write.log; exit 1; }
+find $OUT -name "*.csv" | head -30
+du -sh $OUT

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (written by tools/gpu_profile.sh on the GPU box) into tracked files
+under profiles/: the rocprofv3 --stats kernel table, the PMC traffic per launch corrected as
+MI355X_MICROARCH.md "HBM" prescribes, and the counter calibration that justifies the correction."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", tag)
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+def counters(path):
+    d = collections.defaultdict(list)
+    if not path:
+        return {}
+    for r in csv.DictReader(open(path)):
+        d[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in d.items()}
+
+
+summary = {"tag": tag}
+ks = one("trace/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, "%s_kernel_stats.csv" % tag))
+    rows = list(csv.DictReader(open(ks)))
+    summary["kernel_stats"] = [{"name": r["Name"].split("(")[0], "calls": int(r["Calls"]),
+                                "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows]
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    shutil.copy(bj, os.path.join(dst, "%s_bench.json" % tag))
+    summary["bench"] = json.loads(open(bj).read().strip().splitlines()[-1])
+
+calib = {}
+for which, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
+        if c == ctr and "calib_" in k:
+            calib["%s %s" % (k.split("(")[0].replace("void ", ""), ctr)] = {"launches": n, "counter_KiB": avg,
+                                                                          "known_KiB": 1048576.0,
+                                                                          "bytes_per_count_KiB": 1048576.0 / avg if avg else None}
+summary["calibration"] = calib
+rd = [v["bytes_per_count_KiB"] for k, v in calib.items() if "calib_read" in k and "FETCH" in k]
+wr = [v["bytes_per_count_KiB"] for k, v in calib.items() if "calib_write" in k and "WRITE" in k]
+f_corr = sum(rd) / len(rd) if rd else 2.0
+w_corr = sum(wr) / len(wr) if wr else 1.0
+summary["fetch_correction"] = f_corr
+summary["write_correction"] = w_corr
+traffic = {}
+for which, ctr, corr in (("pmc_fetch", "FETCH_SIZE", f_corr), ("pmc_write", "WRITE_SIZE", w_corr)):
+    for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
+        if c == ctr and k.startswith("void k_"):
+            name = k.split("(")[0].replace("void ", "")
+            traffic.setdefault(name, {})[ctr] = {"launches": n, "counter_KiB": avg, "bytes": avg * 1024.0 * corr}
+for name, t in traffic.items():
+    t["hbm_bytes_per_launch"] = sum(x["bytes"] for x in t.values() if isinstance(x, dict))
+summary["traffic"] = traffic
+json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
+print(json.dumps({k: summary[k] for k in ("kernel_stats", "traffic", "fetch_correction", "write_correction") if k in summary}, indent=1))
