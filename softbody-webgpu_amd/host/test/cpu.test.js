@@ -1,0 +1,116 @@
+'use strict';
+// CPU-side tests of the JavaScript host mirror (run by tests/test_node_host.py with Node 12).
+const assert = require('assert');
+const fs = require('fs');
+const path = require('path');
+const h = require('..');
+
+const GOLDEN = path.resolve(__dirname, '..', '..', '..', 'tests', 'golden');
+const results = [];
+function test(name, fn) {
+    try {
+        const r = fn();
+        if (r && r.then) return r.then(() => results.push(name), (e) => { console.error('FAIL', name, e); process.exitCode = 1; });
+        results.push(name);
+    } catch (e) {
+        console.error('FAIL', name, e);
+        process.exitCode = 1;
+    }
+    return null;
+}
+const same = (ab, file) => Buffer.compare(Buffer.from(ab), fs.readFileSync(path.join(GOLDEN, file))) === 0;
+
+(async () => {
+    test('default scene snapshot bytes, layout 1 (engineMapping.ts:377-401, main.ts:188-246)', () => {
+        const m = h.defaultScene(new h.BufferMapper(1 << 27));
+        assert.strictEqual(m.maxParticles, 65536);
+        assert.strictEqual(m.meta.particleCount, 0);
+        const snap = m.createSnapshotBuffer();
+        assert.strictEqual(m.meta.particleCount, 119);
+        assert.strictEqual(m.meta.beamCount, 299);
+        assert.ok(same(snap, 'default_scene_v1.snapshot'));
+    });
+    test('default scene snapshot bytes, layout 2', () => {
+        const m = h.defaultScene(new h.BufferMapper(1 << 27, { layout: 2, maxParticles: 256, maxBeams: 512 }));
+        assert.ok(same(m.createSnapshotBuffer(), 'default_scene_v2.snapshot'));
+    });
+    test('snapshot load -> object model -> snapshot is the identity', () => {
+        const golden = fs.readFileSync(path.join(GOLDEN, 'default_scene_v1_after_2_frames.snapshot'));
+        const ab = golden.buffer.slice(golden.byteOffset, golden.byteOffset + golden.byteLength);
+        const m = new h.BufferMapper(1 << 27);
+        assert.strictEqual(m.loadSnapshotbuffer(ab), true);
+        assert.strictEqual(m.particleSet.size, 119);
+        assert.strictEqual(m.beamSet.size, 299);
+        const b0 = m.findBeam(0);
+        assert.strictEqual(b0.a, 0);
+        assert.strictEqual(b0.b, 1);
+        assert.ok(same(m.createSnapshotBuffer(), 'default_scene_v1_after_2_frames.snapshot'));
+    });
+    test('record bytes of Particle.to / Beam.to (engineMapping.ts:118-124,178-194)', () => {
+        const m = new h.BufferMapper(4096, { maxParticles: 8, maxBeams: 8 });
+        m.addParticle(new h.Particle(5, new h.Vector2D(1, 2), new h.Vector2D(3, 4), new h.Vector2D(5, 6)));
+        m.addParticle(new h.Particle(9, new h.Vector2D(7, 8)));
+        m.addBeam(new h.Beam(3, 9, 5, 30, 50, 700, 0.2, 0.5, 29, 31));
+        m.writeState();
+        assert.deepStrictEqual(Array.from(new Float32Array(m.particleData, 0, 6)), [1, 2, 3, 4, 5, 6]);
+        assert.deepStrictEqual(Array.from(new Uint16Array(m.mapping, 0, 2)), [0, 1]);
+        assert.deepStrictEqual(Array.from(new Uint16Array(m.beamData, 0, 2)), [1, 0]); // ids 9,5 -> indices 1,0
+        const f = new Float32Array(m.beamData, 4, 7);
+        assert.deepStrictEqual(Array.from(f).map((x) => +x.toFixed(4)), [30, 29, 31, 50, 700, 0.2, 0.5]);
+        const md = new Uint32Array(m.metadata);
+        assert.deepStrictEqual([md[0], md[1], md[5], md[6], md[10], md[11]], [3, 2, 2, 1, 8, 8]);
+        assert.strictEqual(new Float32Array(m.metadata)[13], -0.5);
+    });
+    test('edit API (engineMapping.ts:432-495)', () => {
+        const m = new h.BufferMapper(4096, { maxParticles: 4, maxBeams: 4 });
+        assert.strictEqual(m.firstEmptyParticleId, 0);
+        assert.ok(m.addParticle(new h.Particle(0)));
+        assert.ok(!m.addParticle(new h.Particle(0)));
+        assert.ok(m.addParticle(new h.Particle(2)));
+        assert.strictEqual(m.firstEmptyParticleId, 1);
+        const b = new h.Beam(0, 0, 2, 10, 1, 1, 1, 1);
+        assert.ok(m.addBeam(b));
+        assert.strictEqual(m.getConnectedBeams(2).size, 1);
+        assert.ok(m.removeBeam(0));
+        assert.strictEqual(m.getConnectedBeams(2).size, 0);
+        assert.strictEqual(m.findBeam(0), null);
+        assert.ok(m.removeParticle(2));
+        assert.strictEqual(m.particleSet.size, 1);
+    });
+    test('Vector2D helpers', () => {
+        const v = new h.Vector2D(3, 4);
+        assert.strictEqual(v.magnitude, 5);
+        assert.strictEqual(v.norm().x, 3 * (1 / 5));
+        assert.strictEqual(v.sub(new h.Vector2D(1, 1)).dot(new h.Vector2D(1, 0)), 2);
+        assert.strictEqual(h.Vector2D.turnDirection(new h.Vector2D(0, 0), new h.Vector2D(1, 0), new h.Vector2D(0, 1)), -1);
+        assert.strictEqual(h.Vector2D.clamp(new h.Vector2D(5, -5), h.Vector2D.zero, new h.Vector2D(1, 1)).toString(), 'Vector2D<1, 0>');
+    });
+    await test('AsyncLock is FIFO (lock.ts:4-19)', async () => {
+        const lock = new h.AsyncLock();
+        const order = [];
+        await lock.acquire();
+        const a = lock.acquire().then(() => { order.push('a'); lock.release(); });
+        const b = lock.acquire().then(() => { order.push('b'); lock.release(); });
+        order.push('first');
+        lock.release();
+        await Promise.all([a, b]);
+        assert.deepStrictEqual(order, ['first', 'a', 'b']);
+        await lock.acquire(); // free again
+        lock.release();
+    });
+    test('layout 1 rejects more than 65536 elements; message enum matches engine.ts:3-14', () => {
+        assert.throws(() => new h.BufferMapper(1 << 30, { maxParticles: 70000 }), RangeError);
+        assert.strictEqual(h.WGPUSoftbodyEngineMessageTypes.SNAPSHOT_LOAD, 7);
+        assert.strictEqual(h.WGPUSoftbodyEngineMessageTypes.CORRUPT_BUFFERS, 9);
+    });
+    test('addon loads, exports the C-ABI wrappers, and has no CPU fallback', () => {
+        const a = h.native();
+        for (const f of ['create', 'destroy', 'writeBuffers', 'loadBuffers', 'writeUserInput', 'setPhysicsConstants',
+            'frame', 'step', 'sync', 'stepTimed', 'getCounts', 'getInfo', 'deletePass'])
+            assert.strictEqual(typeof a[f], 'function', f);
+        if (process.env.SOFTBODY_EXPECT_NO_GPU === '1') {
+            assert.throws(() => new h.WGPUSoftbodyEngine({}), /no CPU fallback/);
+        }
+    });
+    console.log(JSON.stringify({ passed: results.length, failed: process.exitCode ? 1 : 0, names: results }));
+})();

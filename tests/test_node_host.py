@@ -1,0 +1,40 @@
+"""The Node host (JavaScript mirror of engine.ts / engineMapping.ts / engineWorker.ts + the N-API addon)."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_TESTS = os.path.join(ROOT, "softbody-webgpu_amd", "host", "test")
+
+needs_node = pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+
+
+def run_node(script, env=None, timeout=300):
+    import __graft_entry__ as ge
+    ge.build()
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run(["node", os.path.join(HOST_TESTS, script)], capture_output=True, text=True, env=e, timeout=timeout)
+    assert p.returncode == 0, "node %s failed:\n%s\n%s" % (script, p.stdout, p.stderr)
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@needs_node
+def test_js_host_cpu():
+    """BufferMapper bytes against the golden snapshots, edit API, lock, addon export surface, and the
+    loud failure without a GPU."""
+    import torch
+    r = run_node("cpu.test.js", {"SOFTBODY_EXPECT_NO_GPU": "0" if torch.cuda.is_available() else "1"})
+    assert r["failed"] == 0 and r["passed"] == 9
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_host_gpu_end_to_end():
+    """Node -> N-API -> C ABI -> HIP: 2 frames of the default scene equal the oracle golden bit for bit;
+    1000 substeps of the config-1 lattice through the worker API."""
+    r = run_node("gpu.test.js")
+    assert r["ok"] and r["info"]["path"] == 2 and r["info"]["tiles"] >= 4
