@@ -5,6 +5,7 @@
 // point needs a live HIP device and fails loudly otherwise.
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 
@@ -359,6 +360,46 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
             if (nc) SB_HIP(e, hipMemcpy(e->beams.ib, c_ib.data(), nc * 4, hipMemcpyHostToDevice));
         }
     }
+    // ---- spatial hash: covers the uploaded bounding box plus a margin; particles that later
+    // leave it are clamped into edge cells (still a superset of the contacts, sb_physics.h)
+    e->grid = SbGrid{};
+    e->ncell = 0;
+    if (e->opt.collision_mode == SB_COLLIDE_GRID) {
+        float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+        for (uint32_t s = 0; s < P; s++) {
+            if (!std::isfinite(px[s]) || !std::isfinite(py[s])) continue;
+            minx = std::min(minx, px[s]); maxx = std::max(maxx, px[s]);
+            miny = std::min(miny, py[s]); maxy = std::max(maxy, py[s]);
+        }
+        if (!(minx <= maxx)) minx = maxx = miny = maxy = 0.f;
+        float cell = e->prm.particle_radius * 2.0f * 1.015625f;
+        const float S = e->prm.bounds_size;
+        float mx = std::max(0.25f * (maxx - minx), 16.f * cell), my = std::max(0.25f * (maxy - miny), 16.f * cell);
+        float x0 = std::max(0.f, minx - mx), x1 = std::min(S, maxx + mx);
+        float y0 = std::max(0.f, miny - my), y1 = std::min(S, maxy + my);
+        if (!(x1 > x0)) x1 = x0 + cell;
+        if (!(y1 > y0)) y1 = y0 + cell;
+        // at most 16384 cells per side and 2^27 cells in all: coarser cells are still a valid broad phase
+        for (;;) {
+            double nxd = std::ceil((double)(x1 - x0) / cell), nyd = std::ceil((double)(y1 - y0) / cell);
+            if (nxd <= 16384.0 && nyd <= 16384.0 && nxd * nyd <= 134217728.0) break;
+            cell *= 1.25f;
+        }
+        e->grid.x0 = x0;
+        e->grid.y0 = y0;
+        e->grid.cell = cell;
+        e->grid.nx = std::max(1u, (uint32_t)std::ceil((double)(x1 - x0) / cell));
+        e->grid.ny = std::max(1u, (uint32_t)std::ceil((double)(y1 - y0) / cell));
+        e->ncell = e->grid.nx * e->grid.ny;
+        uint32_t *scan = nullptr, *boff = nullptr;
+        SB_TRY(dev_alloc(e, &scan, (size_t)e->ncell + 1));
+        SB_TRY(dev_alloc(e, &boff, ((size_t)e->ncell + 1 + SB_SCAN_BLOCK - 1) / SB_SCAN_BLOCK));
+        SB_TRY(dev_alloc(e, &e->d_rank, P));
+        SB_TRY(dev_alloc(e, &e->d_rec, P));
+        e->grid.cell_scan = scan;
+        e->grid.block_off = boff;
+        e->grid.rec = e->d_rec;
+    }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     SB_TRY(dev_alloc(e, &e->d_forces, P));
     SB_HIP(e, hipMemset(e->d_forces, 0, std::max<size_t>(P, 1) * sizeof(int2)));
@@ -588,7 +629,8 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "substeps_done") *value = e->substeps_done;
     else if (k == "lds_bytes") *value = e->lds_bytes;
     else if (k == "kernels_per_substep")
-        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 3 : 0);
+        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 5 : 0);
+    else if (k == "grid_cells") *value = e->ncell;
     else SB_FAIL(e, SB_ERR_INVALID, "sb_get_info: unknown key '%s'", key);
     return SB_OK;
 }

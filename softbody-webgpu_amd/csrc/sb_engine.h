@@ -74,14 +74,13 @@ struct sb_engine {
     uint32_t *d_halo_idx = nullptr;   // internal particle index of each halo entry
     size_t lds_bytes = 0;
 
-    // spatial hash (SB_COLLIDE_GRID)
-    uint32_t grid_n = 0;
-    float grid_cell = 0.f;
-    uint32_t *d_cell_count = nullptr, *d_cell_start = nullptr, *d_cell_of = nullptr;
-    uint32_t *d_sorted_id = nullptr; // internal particle index, sorted by cell
-    float4 *d_sorted_pv = nullptr;   // p,v of the sorted particles
-    void *d_scan_tmp = nullptr;
-    size_t scan_tmp_bytes = 0;
+    // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state every substep
+    SbGrid grid{};
+    uint32_t ncell = 0;              // nx*ny (+1 spare entry in the arrays)
+    uint32_t *d_cell_scan = nullptr; // counts, then in-block exclusive scan
+    uint32_t *d_block_off = nullptr; // per 2048-cell block
+    uint32_t *d_rank = nullptr;      // per particle: arrival rank inside its cell
+    float4 *d_rec = nullptr;         // particles sorted by cell
 
     size_t device_bytes = 0;
     std::vector<void *> allocs;
@@ -92,4 +91,3 @@ void sbk_launch_substep(sb_engine *e);
 void sbk_launch_delete(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float4 *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float4 *src);
-size_t sbk_grid_scan_bytes(uint32_t ncell);

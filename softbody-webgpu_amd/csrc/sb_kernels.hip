@@ -42,7 +42,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
                                                         int2 *forces, uint32_t P,
                                                         const SbConsts *__restrict__ cp, SbParams prm,
                                                         const uint32_t *__restrict__ pidx,
-                                                        const uint8_t *__restrict__ ghost)
+                                                        const uint8_t *__restrict__ ghost, SbGrid grid)
 {
     __shared__ float2 s_pos[SB_BLOCK];
     const SbConsts c = *cp;
@@ -78,6 +78,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
             }
         }
     }
+    if (MODE == SB_COLLIDE_GRID && active)
+        sb_collide_grid(grid, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.vel);
     if (!active) return;
     int2 f = forces[i];
     forces[i] = make_int2(0, 0); // atomicExchange(..., 0), :184-185
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
     const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all,
-    const SbConsts *__restrict__ cp, SbParams prm, uint32_t *broken, const uint8_t *__restrict__ ghost)
+    const SbConsts *__restrict__ cp, SbParams prm, uint32_t *broken, const uint8_t *__restrict__ ghost,
+    const uint32_t *__restrict__ pidx, SbGrid grid)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
@@ -167,11 +170,100 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         particle.p = s_pos[i];
         particle.v = r.vel[g];
         particle.a = r.acc[g];
+        if (MODE == SB_COLLIDE_GRID) {
+            const SbParticle self = particle; // :141
+            sb_collide_grid(grid, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx, r.vel);
+        }
         sb_particle_finish(prm, c, particle, s_f[2 * i], s_f[2 * i + 1]);
         w.pos[g] = particle.p;
         w.vel[g] = particle.v;
         w.acc[g] = particle.a;
     }
+}
+
+
+// ---------------------------------------------------------------- spatial hash build
+
+// counts per cell, and each particle's arrival rank inside its cell (one returning atomic per
+// particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_count(const float2 *__restrict__ pos, uint32_t P, SbGrid g,
+                                                         uint32_t *cell_count, uint32_t *rank)
+{
+    uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    float2 p = pos[i];
+    uint32_t c = sb_grid_coord(p.y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p.x, g.x0, g.cell, g.nx);
+    rank[i] = atomicAdd(&cell_count[c], 1u);
+}
+
+// in-place exclusive scan of each 2048-cell block (256 threads x 8 cells) + the block totals
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell, uint32_t n, uint32_t *block_sum)
+{
+    __shared__ uint32_t s_wave[SB_BLOCK / 64];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * SB_SCAN_BLOCK + tid * 8u;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t x = base + k < n ? cell[base + k] : 0u;
+        v[k] = sum;
+        sum += x;
+    }
+    // inclusive scan of the per-thread sums across the wave, then across the 4 waves
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(inc, off, 64);
+        if ((tid & 63u) >= (uint32_t)off) inc += t;
+    }
+    if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) wave_off += s_wave[w];
+    const uint32_t excl = wave_off + inc - sum;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (base + k < n) cell[base + k] = v[k] + excl;
+    if (tid == SB_BLOCK - 1) block_sum[blockIdx.x] = excl + sum;
+}
+
+// exclusive scan of the block totals, one workgroup walking 256 at a time with a carry
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum, uint32_t nblocks)
+{
+    __shared__ uint32_t s_wave[SB_BLOCK / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += SB_BLOCK) {
+        uint32_t x = base + tid < nblocks ? block_sum[base + tid] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(inc, off, 64);
+            if ((tid & 63u) >= (uint32_t)off) inc += t;
+        }
+        if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t wave_off = s_carry;
+        for (uint32_t w = 0; w < (tid >> 6); w++) wave_off += s_wave[w];
+        if (base + tid < nblocks) block_sum[base + tid] = wave_off + inc - x;
+        __syncthreads();
+        if (tid == SB_BLOCK - 1) s_carry = wave_off + inc;
+        __syncthreads();
+    }
+}
+
+// particles -> records sorted by cell
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scatter(const float2 *__restrict__ pos,
+                                                           const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
+                                                           const uint32_t *__restrict__ rank, float4 *rec)
+{
+    uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    float2 p = pos[i];
+    uint32_t c = sb_grid_coord(p.y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p.x, g.x0, g.cell, g.nx);
+    uint32_t k = sb_grid_start(g, c) + rank[i];
+    rec[k] = make_float4(p.x, p.y, __uint_as_float(pslot[i]), __uint_as_float(i));
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -231,27 +323,39 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 void sbk_launch_substep(sb_engine *e)
 {
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
+    const uint8_t *ghost = e->has_ghosts ? e->d_ghost : nullptr;
+    const uint32_t mode = e->opt.collision_mode;
+    if (mode == SB_COLLIDE_GRID && e->P) {
+        // rebuild the spatial hash from the READ state
+        uint32_t *counts = const_cast<uint32_t *>(e->grid.cell_scan);
+        uint32_t *boff = const_cast<uint32_t *>(e->grid.block_off);
+        const uint32_t n = e->ncell + 1, nblocks = cdiv(n, SB_SCAN_BLOCK);
+        (void)hipMemsetAsync(counts, 0, (size_t)n * 4, e->stream);
+        k_grid_count<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(r.pos, e->P, e->grid, counts, e->d_rank);
+        k_grid_scan_blocks<<<nblocks, SB_BLOCK, 0, e->stream>>>(counts, n, boff);
+        k_grid_scan_sums<<<1, SB_BLOCK, 0, e->stream>>>(boff, nblocks);
+        k_grid_scatter<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(r.pos, e->d_pslot, e->P, e->grid, e->d_rank,
+                                                                       e->d_rec);
+    }
     if (e->path == SB_PATH_ATOMIC) {
         if (e->nbeam)
             k_beams_atomic<<<cdiv(e->nbeam, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->beams, e->nbeam, r.pos,
                                                                                e->d_forces, e->d_broken);
         if (e->P) {
             dim3 g(cdiv(e->P, SB_BLOCK));
-            const uint8_t *ghost = e->has_ghosts ? e->d_ghost : nullptr;
-            if (e->opt.collision_mode == SB_COLLIDE_ALLPAIRS)
-                k_particles<SB_COLLIDE_ALLPAIRS><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts,
-                                                                                e->prm, e->d_pidx, ghost);
-            else
-                k_particles<SB_COLLIDE_OFF><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts,
-                                                                           e->prm, e->d_pidx, ghost);
+#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts, e->prm, e->d_pidx, ghost, e->grid)
+            if (mode == SB_COLLIDE_ALLPAIRS) SB_LAUNCH_P(SB_COLLIDE_ALLPAIRS);
+            else if (mode == SB_COLLIDE_GRID) SB_LAUNCH_P(SB_COLLIDE_GRID);
+            else SB_LAUNCH_P(SB_COLLIDE_OFF);
+#undef SB_LAUNCH_P
         }
-    } else {
-        if (e->ntiles) {
-            const uint8_t *ghost = e->has_ghosts ? e->d_ghost : nullptr;
-            k_substep_tiled<SB_COLLIDE_OFF><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(
-                r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,
-                e->d_consts, e->prm, e->d_broken, ghost);
-        }
+    } else if (e->ntiles) {
+#define SB_LAUNCH_T(M) k_substep_tiled<M><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(                      \
+        r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
+        e->d_consts, e->prm, e->d_broken, ghost, e->d_pidx, e->grid)
+        if (mode == SB_COLLIDE_GRID) SB_LAUNCH_T(SB_COLLIDE_GRID);
+        else SB_LAUNCH_T(SB_COLLIDE_OFF);
+#undef SB_LAUNCH_T
     }
     e->cur ^= 1;
     e->substeps_done++;
@@ -279,4 +383,3 @@ void sbk_launch_halo_unpack(sb_engine *e, const float4 *src)
     k_halo_unpack<<<cdiv(e->n_ghost, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(c.pos, c.vel, e->d_ghost_list, e->n_ghost, src);
 }
 
-size_t sbk_grid_scan_bytes(uint32_t) { return 0; }

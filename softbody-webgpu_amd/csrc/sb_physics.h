@@ -195,6 +195,80 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
     }
 }
 
+// ---------------------------------------------------------------- spatial hash (SB_COLLIDE_GRID)
+
+// Uniform grid over [x0, x0 + nx*cell) x [y0, y0 + ny*cell); coordinates outside are clamped into
+// the edge cells.  The map x -> cell coordinate is monotone and cell >= 2r * (1 + 1/64), so two
+// particles closer than 2r always land in the same or adjacent cells: the 3x3 neighbourhood is a
+// SUPERSET of the interacting pairs of compute.wgsl:144-170 wherever the particles are (clamping
+// only piles far-away particles into edge cells: slower, never wrong).
+struct SbGrid {
+    const uint32_t *cell_scan; // per cell: exclusive scan inside its 2048-cell block
+    const uint32_t *block_off; // per 2048-cell block: offset of the block
+    const float4 *rec;         // sorted by cell: {p.x, p.y, bits(slot), bits(internal index)}
+    float x0, y0, cell;
+    uint32_t nx, ny;
+};
+#define SB_SCAN_BLOCK 2048u
+
+SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
+{
+    float q = sb_div(x - x0, cell);
+    if (!(q > 0.0f)) return 0u; // negative, zero, NaN
+    if (q >= (float)n) return n - 1u;
+    return (uint32_t)q;
+}
+SB_DEV uint32_t sb_grid_start(const SbGrid &g, uint32_t c) { return g.cell_scan[c] + g.block_off[c / SB_SCAN_BLOCK]; }
+
+// The collision loop of compute.wgsl:144-170 restricted to the 3x3 cell neighbourhood, applying
+// contacts in ASCENDING SLOT ORDER exactly like the all-pairs scan does: repeatedly pick the
+// contact with the smallest slot above the last one applied.  Non-contacts are no-ops in the
+// reference loop, so skipping them changes nothing; the result is bit-identical to all-pairs.
+SB_DEV void sb_collide_grid(const SbGrid &g, const SbParams &prm, float friction, float elasticity_coeff,
+                            SbParticle &particle, const SbParticle &self, uint32_t i,
+                            const uint32_t *__restrict__ pidx, const float2 *__restrict__ vel_r)
+{
+    const float two_r = prm.particle_radius * 2.0f;
+    const uint32_t cx = sb_grid_coord(self.p.x, g.x0, g.cell, g.nx);
+    const uint32_t cy = sb_grid_coord(self.p.y, g.y0, g.cell, g.ny);
+    const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < g.nx ? cx + 1u : g.nx - 1u;
+    uint32_t rb[3], re[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        int yy = (int)cy + r - 1;
+        if (yy < 0 || yy >= (int)g.ny) {
+            rb[r] = re[r] = 0u;
+        } else {
+            rb[r] = sb_grid_start(g, (uint32_t)yy * g.nx + xa);
+            re[r] = sb_grid_start(g, (uint32_t)yy * g.nx + xb + 1u); // cell array has one spare entry
+        }
+    }
+    bool have_last = false;
+    uint32_t last = 0u;
+    for (;;) {
+        uint32_t best_slot = 0xFFFFFFFFu, best_id = 0u;
+        float2 best_p = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            for (uint32_t k = rb[r]; k < re[r]; k++) {
+                const float4 rec = g.rec[k];
+                const uint32_t slot = __float_as_uint(rec.z), id = __float_as_uint(rec.w);
+                if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
+                const float d = sb_length(rec.x - self.p.x, rec.y - self.p.y);
+                if (d == 0.0f || d < two_r) {
+                    best_slot = slot;
+                    best_id = id;
+                    best_p = make_float2(rec.x, rec.y);
+                }
+            }
+        }
+        if (best_slot == 0xFFFFFFFFu) break;
+        sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[best_id], best_p, vel_r[best_id]);
+        last = best_slot;
+        have_last = true;
+    }
+}
+
 // everything after the collision loop, compute.wgsl:171-199; fx,fy are the complete fixed-point
 // beam force sums for this particle (the atomicExchange results of :184-185).
 SB_DEV void sb_particle_finish(const SbParams &prm, const SbConsts &c, SbParticle &particle,

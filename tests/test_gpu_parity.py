@@ -177,3 +177,69 @@ def test_errors_are_loud(sb):
     with pytest.raises(sb.engine.EngineError):
         eng.write_buffers(wrong)
     eng.destroy()
+
+
+# ---------------------------------------------------------------- spatial hash (SB_COLLIDE_GRID)
+
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_default_scene_equals_allpairs_oracle(sb, oracle, path):
+    """The GPU spatial hash must give the bits of the reference's all-pairs scan
+    (compute.wgsl:144-170): same pair set, contacts applied in ascending slot order."""
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    got, exp, info = run_both(sb, oracle, buf, frames=3, mode=GRID, ref_mode=ALLPAIRS, path=path, tile=64)
+    assert info["path"] == path
+    assert_same(got, exp, "grid default scene path %d" % path)
+
+
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_particle_soup(sb, oracle, path):
+    """2000 free particles at ~30 % area coverage with random velocities, one coincident pair and a
+    few particles outside the box: many simultaneous contacts per particle."""
+    rng = np.random.default_rng(11)
+    P = 2000
+    pts = np.zeros((P, 6), "f4")
+    pts[:, :2] = rng.uniform(10, 1390, (P, 2))
+    pts[:, 2:4] = rng.uniform(-6, 6, (P, 2))
+    pts[7, :2] = pts[3, :2]
+    pts[100, :2] = (-50.0, 700.0)
+    pts[101, :2] = (1500.0, 1450.0)
+    buf = sb.Buffers(2, P, 4)
+    buf.set_scene(pts, np.zeros(0, sb.layout.BEAM_DTYPE[2]))
+    got, exp, _ = run_both(sb, oracle, buf, n=96, mode=GRID, ref_mode=ALLPAIRS, path=path, bounds=1400.0, tile=128)
+    assert_same(got, exp, "soup path %d" % path)
+    assert not np.array_equal(got.particles[:, 2:4], pts[:, 2:4])
+
+
+def two_blob_scene(sb):
+    """Blob A (64x32 lattice) resting on the floor, blob B (48x24) dropped onto it, 300 free
+    particles raining in: beams + inter-blob contacts + floor/wall response together."""
+    pa, ba = sb.scenes.rectangle(60.0, 11.0, 30.0, 64, 32, 50, 700, 0.2, 1e9, base=0, anti_diagonal=False, layout=2)
+    pb, bb = sb.scenes.rectangle(215.0, 11.0 + 31 * 30 + 24.0, 30.0, 48, 24, 50, 700, 0.2, 1e9, base=pa.shape[0],
+                                 anti_diagonal=False, layout=2)
+    rng = np.random.default_rng(5)
+    nf = 300
+    P = np.zeros((pa.shape[0] + pb.shape[0] + nf, 6), "f4")
+    P[:pa.shape[0], :2] = pa
+    P[pa.shape[0]:pa.shape[0] + pb.shape[0], :2] = pb
+    P[-nf:, :2] = rng.uniform([100, 1700], [1900, 2100], (nf, 2)).astype("f4")
+    P[pa.shape[0]:pa.shape[0] + pb.shape[0], 3] = -3.0
+    P[-nf:, 2:4] = rng.uniform(-3, 3, (nf, 2))
+    P[-nf:, 3] -= 20
+    P[:, :2] += (sb.scenes.hash_uniform(9, P.shape[0] * 2).reshape(-1, 2) * 0.3).astype("f4")
+    B = np.concatenate([ba, bb])
+    buf = sb.Buffers(2, P.shape[0], B.shape[0])
+    buf.set_scene(P, B)
+    return buf
+
+
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_two_blobs_and_rain(sb, oracle, path):
+    """BASELINE config 3 in small (3500 particles): grid collisions + beams + border, 256 substeps,
+    against the oracle's grid mode (itself bit-identical to all-pairs, tests/test_oracle_kat.py).
+    The scene stays finite: NaN sign/payload bits are hardware-specific and not part of parity."""
+    buf = two_blob_scene(sb)
+    got, exp, info = run_both(sb, oracle, buf, n=256, mode=GRID, path=path, bounds=4000.0, tile=256)
+    assert np.isfinite(exp.particles).all()
+    assert_same(got, exp, "two blobs path %d" % path)
+    off, _, _ = run_both(sb, oracle, buf, n=256, mode=OFF, path=path, bounds=4000.0, tile=256)
+    assert (off.particles != got.particles).any(axis=1).sum() > 1000  # collisions really acted
