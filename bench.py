@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--collisions", choices=["off", "grid"], default="off")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--ghost-depth", type=int, default=16,
+                    help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -125,14 +127,19 @@ def main():
         buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0, layout=2)
         plan = None
     else:
-        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0)
+        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0,
+                                    depth=a.ghost_depth)
     P_local = buf.particle_count if plan is None else plan.n_owned
-    B_local = buf.beam_count
+    B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=64, layout=2,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
                     path=path, tile_particles=a.tile, device=local)
     eng.write_buffers(buf)
-    stepper = eng.step if plan is None else halo.Exchanger(sb, eng, plan, dist, torch).step
+    if plan is None:
+        stepper = eng.step
+    else:
+        transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream())
+        stepper = halo.Exchanger(eng, plan, transport).step
 
     def barrier():
         if dist is not None:
@@ -190,7 +197,9 @@ def main():
             "config": {"workload": workload,
                        "particles_total": P_total, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
                        "tiles": eng.info("tiles"),
-                       "parallelism": "single GPU" if world == 1 else "%d x-slabs, ghost p,v exchange per substep over RCCL" % world},
+                       "parallelism": "single GPU" if world == 1 else
+                       "%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, RCCL neighbour "
+                       "send/recv of ghost p,v,a + beam target/last every %d substeps" % (world, W, a.ghost_depth, a.ghost_depth)},
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:

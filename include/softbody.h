@@ -146,17 +146,23 @@ sb_status sb_get_counts(sb_engine *e, uint32_t *particles, uint32_t *beams);
  * "device_bytes", "substeps_done", "kernels_per_substep". */
 sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value);
 
-/* ---- multi-GPU halo exchange; one engine per rank/GPU.
- * Ghost particles are particles in this engine's scene that another rank owns: they are
- * never integrated here; their p,v are overwritten from the owner before every substep.
- * Lists are DATA indices into this engine's particle buffer. */
-sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_indices, uint32_t n_ghost,
-                            const uint32_t *send_indices, uint32_t n_send);
-/* pack p,v (4 floats each) of the send list from the current particle buffer into a DEVICE
- * buffer of n_send*16 bytes, on the engine's stream. */
+/* ---- multi-GPU halo exchange; one engine per rank/GPU, each holding its
+ * slab of the scene PLUS a ghost zone k beam-hops deep copied from its neighbours.  Ghost
+ * particles and ghost beams are stepped like any others (redundantly; the arithmetic is
+ * deterministic, so the copies agree bit for bit while their inputs are valid); every k substeps
+ * the owners overwrite them: p,v,a (6 floats) per ghost particle, target_length,last_length
+ * (2 floats) per ghost beam.  Lists are DATA indices into this engine's particle / beam buffers,
+ * in the order the peer packs them.  The exchange itself (RCCL send/recv on the packed device
+ * buffers) is the caller's; see softbody-webgpu_amd/halo.py. */
+sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_particles, uint32_t n_ghost_particles,
+                            const uint32_t *send_particles, uint32_t n_send_particles,
+                            const uint32_t *ghost_beams, uint32_t n_ghost_beams,
+                            const uint32_t *send_beams, uint32_t n_send_beams);
+/* current state of the send lists -> DEVICE buffer of (6*n_send_particles + 2*n_send_beams) floats
+ * (particles first), enqueued on the engine's stream. */
 sb_status sb_halo_pack(sb_engine *e, void *device_dst);
-/* overwrite p,v of the ghost list in the current particle buffer from a DEVICE buffer of
- * n_ghost*16 bytes, on the engine's stream. */
+/* DEVICE buffer of (6*n_ghost_particles + 2*n_ghost_beams) floats -> current state of the ghost
+ * lists, enqueued on the engine's stream. */
 sb_status sb_halo_unpack(sb_engine *e, const void *device_src);
 /* the engine's hipStream_t, so a caller can order its own work (RCCL send/recv) after it. */
 sb_status sb_get_stream(sb_engine *e, void **hip_stream);

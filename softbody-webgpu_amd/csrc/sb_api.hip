@@ -54,8 +54,7 @@ static void free_scene(sb_engine *e)
     e->allocs.clear();
     e->device_bytes = 0;
     e->loaded = false;
-    e->has_ghosts = false;
-    e->n_ghost = e->n_send = 0;
+    e->n_ghost_p = e->n_send_p = e->n_ghost_b = e->n_send_b = e->n_ghost_b_copies = 0;
 }
 
 static inline uint32_t beam_stride(const sb_engine *e)
@@ -296,8 +295,6 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         SB_TRY(dev_alloc(e, &e->d_pslot, P));
         SB_HIP(e, hipMemcpy(e->d_pidx, e->h_pidx.data(), P * 4, hipMemcpyHostToDevice));
         SB_HIP(e, hipMemcpy(e->d_pslot, e->h_pslot.data(), P * 4, hipMemcpyHostToDevice));
-        SB_TRY(dev_alloc(e, &e->d_ghost, P));
-        SB_HIP(e, hipMemset(e->d_ghost, 0, std::max<size_t>(P, 1)));
     }
 
     // ---- beam copies
@@ -635,37 +632,60 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     return SB_OK;
 }
 
-sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_indices, uint32_t n_ghost,
-                            const uint32_t *send_indices, uint32_t n_send)
+sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_particles, uint32_t n_gp,
+                            const uint32_t *send_particles, uint32_t n_sp, const uint32_t *ghost_beams,
+                            uint32_t n_gb, const uint32_t *send_beams, uint32_t n_sb)
 {
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_configure before sb_write_buffers");
-    if ((n_ghost && !ghost_indices) || (n_send && !send_indices)) SB_FAIL(e, SB_ERR_INVALID, "null index list");
+    if ((n_gp && !ghost_particles) || (n_sp && !send_particles) || (n_gb && !ghost_beams) || (n_sb && !send_beams))
+        SB_FAIL(e, SB_ERR_INVALID, "null index list");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
-    std::vector<uint32_t> internal_of_index(e->opt.max_particles, 0xFFFFFFFFu);
+    const uint32_t maxP = e->opt.max_particles, maxB = e->opt.max_beams;
+    std::vector<uint32_t> internal_of_index(maxP, 0xFFFFFFFFu), slot_of_beam(maxB, 0xFFFFFFFFu);
     for (uint32_t i = 0; i < e->P; i++) internal_of_index[e->h_pidx[i]] = i;
-    auto translate = [&](const uint32_t *src, uint32_t n, std::vector<uint32_t> &dst) -> bool {
+    for (uint32_t s = 0; s < e->B; s++) slot_of_beam[map_get(e, e->h_mapping.data(), (size_t)maxP + s)] = s;
+    auto translate = [](const uint32_t *src, uint32_t n, const std::vector<uint32_t> &table, std::vector<uint32_t> &dst) {
         dst.resize(n);
         for (uint32_t k = 0; k < n; k++) {
-            if (src[k] >= e->opt.max_particles || internal_of_index[src[k]] == 0xFFFFFFFFu) return false;
-            dst[k] = internal_of_index[src[k]];
+            if (src[k] >= table.size() || table[src[k]] == 0xFFFFFFFFu) return false;
+            dst[k] = table[src[k]];
         }
         return true;
     };
-    std::vector<uint32_t> g, s;
-    if (!translate(ghost_indices, n_ghost, g) || !translate(send_indices, n_send, s))
+    std::vector<uint32_t> gp, sp, gb, sbm;
+    if (!translate(ghost_particles, n_gp, internal_of_index, gp) || !translate(send_particles, n_sp, internal_of_index, sp))
         SB_FAIL(e, SB_ERR_INVALID, "halo list names a particle data index that is not active");
-    std::vector<uint8_t> flags(e->P, 0);
-    for (uint32_t i : g) flags[i] = 1;
-    if (e->P) SB_HIP(e, hipMemcpy(e->d_ghost, flags.data(), e->P, hipMemcpyHostToDevice));
-    SB_TRY(dev_alloc(e, &e->d_ghost_list, n_ghost));
-    SB_TRY(dev_alloc(e, &e->d_send_list, n_send));
-    if (n_ghost) SB_HIP(e, hipMemcpy(e->d_ghost_list, g.data(), n_ghost * 4, hipMemcpyHostToDevice));
-    if (n_send) SB_HIP(e, hipMemcpy(e->d_send_list, s.data(), n_send * 4, hipMemcpyHostToDevice));
-    e->n_ghost = n_ghost;
-    e->n_send = n_send;
-    e->has_ghosts = n_ghost > 0;
+    if (!translate(ghost_beams, n_gb, slot_of_beam, gb) || !translate(send_beams, n_sb, slot_of_beam, sbm))
+        SB_FAIL(e, SB_ERR_INVALID, "halo list names a beam data index that is not active");
+    // sent beams: any one copy (all copies of a valid beam are identical)
+    std::vector<uint32_t> send_copy(n_sb);
+    for (uint32_t k = 0; k < n_sb; k++) send_copy[k] = e->h_copy_of_slot[sbm[k]];
+    // ghost beams: every copy
+    std::vector<uint32_t> pos_of_slot(e->B, 0xFFFFFFFFu);
+    for (uint32_t k = 0; k < n_gb; k++) pos_of_slot[gb[k]] = k;
+    std::vector<uint32_t> copy_slot(e->nbeam);
+    if (e->nbeam) SB_HIP(e, hipMemcpy(copy_slot.data(), e->beams.slot, (size_t)e->nbeam * 4, hipMemcpyDeviceToHost));
+    std::vector<uint2> ghost_copies;
+    for (uint32_t c = 0; c < e->nbeam; c++) {
+        uint32_t s = copy_slot[c];
+        if (s != 0xFFFFFFFFu && pos_of_slot[s] != 0xFFFFFFFFu) ghost_copies.push_back(make_uint2(c, pos_of_slot[s]));
+    }
+    SB_TRY(dev_alloc(e, &e->d_ghost_p, n_gp));
+    SB_TRY(dev_alloc(e, &e->d_send_p, n_sp));
+    SB_TRY(dev_alloc(e, &e->d_send_b, n_sb));
+    SB_TRY(dev_alloc(e, &e->d_ghost_b, ghost_copies.size()));
+    if (n_gp) SB_HIP(e, hipMemcpy(e->d_ghost_p, gp.data(), (size_t)n_gp * 4, hipMemcpyHostToDevice));
+    if (n_sp) SB_HIP(e, hipMemcpy(e->d_send_p, sp.data(), (size_t)n_sp * 4, hipMemcpyHostToDevice));
+    if (n_sb) SB_HIP(e, hipMemcpy(e->d_send_b, send_copy.data(), (size_t)n_sb * 4, hipMemcpyHostToDevice));
+    if (!ghost_copies.empty())
+        SB_HIP(e, hipMemcpy(e->d_ghost_b, ghost_copies.data(), ghost_copies.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    e->n_ghost_p = n_gp;
+    e->n_send_p = n_sp;
+    e->n_ghost_b = n_gb;
+    e->n_send_b = n_sb;
+    e->n_ghost_b_copies = (uint32_t)ghost_copies.size();
     return SB_OK;
 }
 
@@ -673,9 +693,9 @@ sb_status sb_halo_pack(sb_engine *e, void *device_dst)
 {
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_pack before sb_write_buffers");
-    if (e->n_send && !device_dst) SB_FAIL(e, SB_ERR_INVALID, "null device buffer");
+    if ((e->n_send_p || e->n_send_b) && !device_dst) SB_FAIL(e, SB_ERR_INVALID, "null device buffer");
     SB_HIP(e, hipSetDevice(e->device));
-    sbk_launch_halo_pack(e, (float4 *)device_dst);
+    sbk_launch_halo_pack(e, (float *)device_dst);
     SB_HIP(e, hipGetLastError());
     return SB_OK;
 }
@@ -684,9 +704,9 @@ sb_status sb_halo_unpack(sb_engine *e, const void *device_src)
 {
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_unpack before sb_write_buffers");
-    if (e->n_ghost && !device_src) SB_FAIL(e, SB_ERR_INVALID, "null device buffer");
+    if ((e->n_ghost_p || e->n_ghost_b) && !device_src) SB_FAIL(e, SB_ERR_INVALID, "null device buffer");
     SB_HIP(e, hipSetDevice(e->device));
-    sbk_launch_halo_unpack(e, (const float4 *)device_src);
+    sbk_launch_halo_unpack(e, (const float *)device_src);
     SB_HIP(e, hipGetLastError());
     return SB_OK;
 }

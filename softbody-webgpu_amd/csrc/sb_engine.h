@@ -60,10 +60,12 @@ struct sb_engine {
     uint32_t *d_dead_gen = nullptr;  // per beam slot: number of the delete pass that removed it (0 = live)
     uint32_t delete_gen = 0;
     uint32_t *d_flags = nullptr;   // [0] = any beam flagged since the last delete pass
-    uint8_t *d_ghost = nullptr;    // per internal particle: 1 = owned by another rank
-    bool has_ghosts = false;
-    uint32_t *d_ghost_list = nullptr, *d_send_list = nullptr; // internal indices
-    uint32_t n_ghost = 0, n_send = 0;
+    // halo exchange lists (internal particle indices; beam copy indices)
+    uint32_t *d_ghost_p = nullptr, *d_send_p = nullptr;
+    uint32_t n_ghost_p = 0, n_send_p = 0;
+    uint32_t *d_send_b = nullptr;      // one copy per sent beam
+    uint2 *d_ghost_b = nullptr;        // (copy index, position in the ghost beam list), every copy
+    uint32_t n_ghost_b = 0, n_send_b = 0, n_ghost_b_copies = 0;
 
     // tiled path
     uint32_t ntiles = 0, tile_cap_own = 0, tile_cap_all = 0;
@@ -89,5 +91,5 @@ struct sb_engine {
 // sb_kernels.hip
 void sbk_launch_substep(sb_engine *e);
 void sbk_launch_delete(sb_engine *e);
-void sbk_launch_halo_pack(sb_engine *e, float4 *dst);
-void sbk_launch_halo_unpack(sb_engine *e, const float4 *src);
+void sbk_launch_halo_pack(sb_engine *e, float *dst);
+void sbk_launch_halo_unpack(sb_engine *e, const float *src);

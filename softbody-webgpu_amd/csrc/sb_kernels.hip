@@ -41,8 +41,7 @@ template <int MODE>
 __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbParticleArrays w,
                                                         int2 *forces, uint32_t P,
                                                         const SbConsts *__restrict__ cp, SbParams prm,
-                                                        const uint32_t *__restrict__ pidx,
-                                                        const uint8_t *__restrict__ ghost, SbGrid grid)
+                                                        const uint32_t *__restrict__ pidx, SbGrid grid)
 {
     __shared__ float2 s_pos[SB_BLOCK];
     const SbConsts c = *cp;
@@ -83,7 +82,6 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
     if (!active) return;
     int2 f = forces[i];
     forces[i] = make_int2(0, 0); // atomicExchange(..., 0), :184-185
-    if (ghost && ghost[i]) return;
     sb_particle_finish(prm, c, particle, f.x, f.y);
     w.pos[i] = particle.p;
     w.vel[i] = particle.v;
@@ -117,8 +115,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
     const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all,
-    const SbConsts *__restrict__ cp, SbParams prm, uint32_t *broken, const uint8_t *__restrict__ ghost,
-    const uint32_t *__restrict__ pidx, SbGrid grid)
+    const SbConsts *__restrict__ cp, SbParams prm, uint32_t *broken, const uint32_t *__restrict__ pidx,
+    SbGrid grid)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
@@ -165,7 +163,6 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     const SbConsts c = *cp;
     for (uint32_t i = tid; i < n_own; i += SB_BLOCK) {
         const uint32_t g = p0 + i;
-        if (ghost && ghost[g]) continue;
         SbParticle particle;
         particle.p = s_pos[i];
         particle.v = r.vel[g];
@@ -292,28 +289,44 @@ __global__ __launch_bounds__(SB_BLOCK) void k_delete(SbBeamArrays b, uint32_t nw
 
 // ---------------------------------------------------------------- halo exchange helpers
 
-__global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(const float2 *__restrict__ pos,
-                                                        const float2 *__restrict__ vel,
-                                                        const uint32_t *__restrict__ list, uint32_t n,
-                                                        float4 *dst)
+// send lists -> packed float buffer: [6 floats per particle][2 floats per beam]
+__global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(SbParticleArrays c, SbBeamArrays b,
+                                                        const uint32_t *__restrict__ plist, uint32_t np,
+                                                        const uint32_t *__restrict__ blist, uint32_t nb, float *dst)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (k >= n) return;
-    uint32_t i = list[k];
-    float2 p = pos[i], v = vel[i];
-    dst[k] = make_float4(p.x, p.y, v.x, v.y);
+    if (k < np) {
+        uint32_t i = plist[k];
+        float2 p = c.pos[i], v = c.vel[i], a = c.acc[i];
+        float2 *o = (float2 *)(dst + 6 * (size_t)k);
+        o[0] = p;
+        o[1] = v;
+        o[2] = a;
+    } else if (k < np + nb) {
+        uint32_t j = k - np, cpy = blist[j];
+        *(float2 *)(dst + 6 * (size_t)np + 2 * (size_t)j) = make_float2(b.target[cpy], b.last[cpy]);
+    }
 }
 
-__global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(float2 *pos, float2 *vel,
-                                                          const uint32_t *__restrict__ list, uint32_t n,
-                                                          const float4 *__restrict__ src)
+// packed float buffer -> ghost lists (every device copy of a ghost beam is refreshed)
+__global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, SbBeamArrays b,
+                                                          const uint32_t *__restrict__ plist, uint32_t np,
+                                                          const uint2 *__restrict__ blist, uint32_t nbc,
+                                                          const float *__restrict__ src)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (k >= n) return;
-    uint32_t i = list[k];
-    float4 s = src[k];
-    pos[i] = make_float2(s.x, s.y);
-    vel[i] = make_float2(s.z, s.w);
+    if (k < np) {
+        uint32_t i = plist[k];
+        const float2 *in = (const float2 *)(src + 6 * (size_t)k);
+        c.pos[i] = in[0];
+        c.vel[i] = in[1];
+        c.acc[i] = in[2];
+    } else if (k < np + nbc) {
+        uint2 e = blist[k - np];
+        float2 tl = *(const float2 *)(src + 6 * (size_t)np + 2 * (size_t)e.y);
+        b.target[e.x] = tl.x;
+        b.last[e.x] = tl.y;
+    }
 }
 
 // ---------------------------------------------------------------- launchers
@@ -323,7 +336,6 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 void sbk_launch_substep(sb_engine *e)
 {
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
-    const uint8_t *ghost = e->has_ghosts ? e->d_ghost : nullptr;
     const uint32_t mode = e->opt.collision_mode;
     if (mode == SB_COLLIDE_GRID && e->P) {
         // rebuild the spatial hash from the READ state
@@ -343,7 +355,7 @@ void sbk_launch_substep(sb_engine *e)
                                                                                e->d_forces, e->d_broken);
         if (e->P) {
             dim3 g(cdiv(e->P, SB_BLOCK));
-#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts, e->prm, e->d_pidx, ghost, e->grid)
+#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts, e->prm, e->d_pidx, e->grid)
             if (mode == SB_COLLIDE_ALLPAIRS) SB_LAUNCH_P(SB_COLLIDE_ALLPAIRS);
             else if (mode == SB_COLLIDE_GRID) SB_LAUNCH_P(SB_COLLIDE_GRID);
             else SB_LAUNCH_P(SB_COLLIDE_OFF);
@@ -352,7 +364,7 @@ void sbk_launch_substep(sb_engine *e)
     } else if (e->ntiles) {
 #define SB_LAUNCH_T(M) k_substep_tiled<M><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(                      \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
-        e->d_consts, e->prm, e->d_broken, ghost, e->d_pidx, e->grid)
+        e->d_consts, e->prm, e->d_broken, e->d_pidx, e->grid)
         if (mode == SB_COLLIDE_GRID) SB_LAUNCH_T(SB_COLLIDE_GRID);
         else SB_LAUNCH_T(SB_COLLIDE_OFF);
 #undef SB_LAUNCH_T
@@ -369,17 +381,18 @@ void sbk_launch_delete(sb_engine *e)
                                                                  e->d_dead_gen, ++e->delete_gen, e->path == SB_PATH_TILED);
 }
 
-void sbk_launch_halo_pack(sb_engine *e, float4 *dst)
+void sbk_launch_halo_pack(sb_engine *e, float *dst)
 {
-    if (!e->n_send) return;
-    SbParticleArrays c = e->part[e->cur];
-    k_halo_pack<<<cdiv(e->n_send, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(c.pos, c.vel, e->d_send_list, e->n_send, dst);
+    uint32_t n = e->n_send_p + e->n_send_b;
+    if (!n) return;
+    k_halo_pack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p, e->n_send_p,
+                                                              e->d_send_b, e->n_send_b, dst);
 }
 
-void sbk_launch_halo_unpack(sb_engine *e, const float4 *src)
+void sbk_launch_halo_unpack(sb_engine *e, const float *src)
 {
-    if (!e->n_ghost) return;
-    SbParticleArrays c = e->part[e->cur];
-    k_halo_unpack<<<cdiv(e->n_ghost, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(c.pos, c.vel, e->d_ghost_list, e->n_ghost, src);
+    uint32_t n = e->n_ghost_p + e->n_ghost_b_copies;
+    if (!n) return;
+    k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->n_ghost_p,
+                                                                e->d_ghost_b, e->n_ghost_b_copies, src);
 }
-

@@ -56,6 +56,16 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64.so.1 and load them by path; if this library pulled in /opt/rocm's copies
+    # first, a later `import torch` would bring up a SECOND runtime in the process, whose device
+    # discovery fails ("No HIP GPUs are available").  Loading torch's copy first makes our
+    # DT_NEEDED libamdhip64.so.7 resolve to the already-loaded one, so torch (RCCL, streams) and the
+    # engine share a single runtime and can share hipStream_t handles (halo.TorchTransport).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     if missing:
@@ -77,7 +87,7 @@ def load_library():
     L.sb_step_timed.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_float)]
     L.sb_get_counts.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.sb_get_info.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
-    L.sb_halo_configure.argtypes = [vp, vp, u32, vp, u32]
+    L.sb_halo_configure.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
     L.sb_halo_pack.argtypes = [vp, vp]
     L.sb_halo_unpack.argtypes = [vp, vp]
     L.sb_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
@@ -184,10 +194,10 @@ class Engine:
         self._check(load_library().sb_get_info(self._h, key.encode(), ctypes.byref(v)))
         return v.value
 
-    def halo_configure(self, ghost_indices, send_indices):
-        g = np.ascontiguousarray(ghost_indices, dtype="<u4")
-        s = np.ascontiguousarray(send_indices, dtype="<u4")
-        self._check(load_library().sb_halo_configure(self._h, _ptr(g), g.size, _ptr(s), s.size))
+    def halo_configure(self, ghost_particles, send_particles, ghost_beams=(), send_beams=()):
+        a = [np.ascontiguousarray(x, dtype="<u4") for x in (ghost_particles, send_particles, ghost_beams, send_beams)]
+        self._check(load_library().sb_halo_configure(self._h, _ptr(a[0]), a[0].size, _ptr(a[1]), a[1].size,
+                                                     _ptr(a[2]), a[2].size, _ptr(a[3]), a[3].size))
 
     def halo_pack(self, device_ptr):
         self._check(load_library().sb_halo_pack(self._h, ctypes.c_void_p(device_ptr)))

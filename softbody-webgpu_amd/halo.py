@@ -1,0 +1,214 @@
+"""Multi-GPU sharding of the physics step: x-slabs with deep ghost zones.
+
+One process / one engine per GPU.  Rank r owns W lattice columns; its engine also holds a ghost
+zone `depth` columns deep on each interior side, copied from the neighbour that owns them.  Ghost
+particles and ghost beams are stepped redundantly (deterministic arithmetic: bit-identical to the
+owner's copy while their inputs are valid).  Invalid data enters at the outer edge of a ghost zone
+and moves one beam hop per substep, so the owned slab sees only valid neighbours for `depth`
+substeps; then the owners refresh the whole zone: p,v,a of every ghost particle and
+target_length/last_length of every ghost beam.  One exchange per `depth` substeps instead of one
+per substep: the exchange is latency-bound (a few hundred KB over 2 of the 7 xGMI links), so
+amortising it is what keeps weak scaling near-linear; the price is depth/W redundant work.
+
+The only collective on the data path is the neighbour send/recv (RCCL through torch.distributed,
+ordered on the engine's own HIP stream); there is no all-reduce.  Collisions across slab faces
+are not handled here (BASELINE configs 4-5 derive from config 2: collisions off).
+"""
+import numpy as np
+
+from . import scenes
+from .layout import LAYOUT_V2, Buffers
+
+
+def hash_at(seed, idx):
+    """scenes.hash_uniform evaluated at arbitrary indices (same splitmix64 stream)."""
+    x = (np.uint64(seed) << np.uint64(32)) + np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(11)).astype(np.float64) / float(1 << 52) - 1.0
+
+
+class Peer:
+    def __init__(self, rank, ghost_p, send_p, ghost_b, send_b):
+        self.rank = rank
+        self.ghost_p, self.send_p, self.ghost_b, self.send_b = ghost_p, send_p, ghost_b, send_b
+
+
+class HaloPlan:
+    """Who owns what on one rank, and what it trades with each neighbour."""
+
+    def __init__(self, rank, world, depth, n_local, owned_particles, owned_beams, peers, global_particle_id,
+                 global_beam_key):
+        self.rank, self.world, self.depth = rank, world, depth
+        self.n_local = n_local
+        self.owned_particles = owned_particles          # local data indices
+        self.owned_beams = owned_beams                  # local beam data indices (endpoint A owned)
+        self.n_owned = int(owned_particles.size)
+        self.peers = peers
+        self.global_particle_id = global_particle_id    # per local particle
+        self.global_beam_key = global_beam_key          # per local beam: (global id of A) * 4 + kind
+
+    def lists(self):
+        cat = lambda xs: np.concatenate(xs).astype("<u4") if xs else np.zeros(0, "<u4")  # noqa: E731
+        return (cat([p.ghost_p for p in self.peers]), cat([p.send_p for p in self.peers]),
+                cat([p.ghost_b for p in self.peers]), cat([p.send_b for p in self.peers]))
+
+    def segments(self):
+        """Per peer: float offsets/lengths inside the packed send and recv buffers
+        (layout: all particles x6 floats, then all beams x2 floats; peers in order)."""
+        gp, sp, gb, sb_ = self.lists()
+        out = []
+        so_p = ro_p = 0
+        so_b, ro_b = 6 * sp.size, 6 * gp.size
+        for p in self.peers:
+            out.append(dict(rank=p.rank,
+                            send=[(so_p, 6 * p.send_p.size), (so_b, 2 * p.send_b.size)],
+                            recv=[(ro_p, 6 * p.ghost_p.size), (ro_b, 2 * p.ghost_b.size)]))
+            so_p += 6 * p.send_p.size
+            ro_p += 6 * p.ghost_p.size
+            so_b += 2 * p.send_b.size
+            ro_b += 2 * p.ghost_b.size
+        return out, 6 * sp.size + 2 * sb_.size, 6 * gp.size + 2 * gb.size
+
+
+def slab_scene(sb, rank, world, W, H, d=30.0, origin=(1000.0, 1000.0), jitter=0.0, depth=8, seed=1,
+               spring=50.0, damp=700.0, yield_strain=0.2, strain_limit=1.0e9, velocity=None):
+    """Rank `rank`'s share of one (W*world) x H lattice blob (3-beam topology, BASELINE configs 2/4):
+    W owned columns plus `depth` ghost columns per interior side.  With world == 1 this is exactly
+    scenes.lattice_buffers(W, H, ...).  Returns (Buffers, HaloPlan)."""
+    if world > 1 and depth > W:
+        raise ValueError("ghost depth %d exceeds the slab width %d" % (depth, W))
+    kL = depth if rank > 0 else 0
+    kR = depth if rank < world - 1 else 0
+    c0 = rank * W - kL                      # global column of local column 0
+    ncol = kL + W + kR
+    p, beams = scenes.rectangle(origin[0] + c0 * float(d), origin[1], d, ncol, H, spring, damp, yield_strain,
+                                strain_limit, anti_diagonal=False, layout=LAYOUT_V2)
+    # positions must be bit-identical to the single-blob scene: recompute from GLOBAL columns
+    xl = np.repeat(np.arange(ncol), H)
+    yl = np.tile(np.arange(H), ncol)
+    gcol = xl + c0
+    gid = gcol.astype(np.int64) * H + yl
+    pv = np.zeros((ncol * H, 6), dtype="<f4")
+    pv[:, 0] = (gcol * float(d) + float(origin[0])).astype("<f4")
+    pv[:, 1] = (yl * float(d) + float(origin[1])).astype("<f4")
+    if jitter:
+        jx = hash_at(seed, 2 * gid).astype("<f4") * np.float32(jitter)
+        jy = hash_at(seed, 2 * gid + 1).astype("<f4") * np.float32(jitter)
+        pv[:, 0] += jx
+        pv[:, 1] += jy
+    if velocity is not None:
+        pv[:, 2:4] = np.asarray(velocity, dtype="<f4")
+    buf = Buffers(LAYOUT_V2, pv.shape[0], beams.shape[0])
+    buf.set_scene(pv, beams)
+
+    col_a = beams["a"].astype(np.int64) // H
+    col_b = beams["b"].astype(np.int64) // H
+    a_loc = beams["a"].astype(np.int64)
+    kind = np.where(beams["b"] == beams["a"] + 1, 0, np.where(beams["b"] == beams["a"] + H, 1, 2))
+    beam_key = gid[a_loc] * 4 + kind
+    pcol = xl
+    owned_p = np.nonzero((pcol >= kL) & (pcol < kL + W))[0].astype("<u4")
+    owned_b = np.nonzero((col_a >= kL) & (col_a < kL + W))[0].astype("<u4")
+
+    def band_particles(lo, hi):
+        return np.nonzero((pcol >= lo) & (pcol < hi))[0].astype("<u4")
+
+    def band_beams(lo, hi):
+        return np.nonzero((col_a >= lo) & (col_a < hi) & (col_b >= lo) & (col_b < hi))[0].astype("<u4")
+
+    peers = []
+    if kL:
+        peers.append(Peer(rank - 1, band_particles(0, kL), band_particles(kL, kL + depth),
+                          band_beams(0, kL), band_beams(kL, kL + depth)))
+    if kR:
+        peers.append(Peer(rank + 1, band_particles(kL + W, ncol), band_particles(kL + W - depth, kL + W),
+                          band_beams(kL + W, ncol), band_beams(kL + W - depth, kL + W)))
+    plan = HaloPlan(rank, world, depth if world > 1 else 0, pv.shape[0], owned_p, owned_b, peers, gid, beam_key)
+    return buf, plan
+
+
+class Exchanger:
+    """Steps one rank's engine and refreshes its ghost zone every `plan.depth` substeps.
+
+    `engine` needs step(n), halo_pack(ptr), halo_unpack(ptr); `transport` moves the packed
+    buffers: TorchTransport for real ranks (torch.distributed P2P, nccl=RCCL on GPU tensors, gloo on
+    CPU tensors), or a test double."""
+
+    def __init__(self, engine, plan, transport):
+        self.engine, self.plan, self.transport = engine, plan, transport
+        self.since = 0
+        gp, sp, gb, sb_ = plan.lists()
+        engine.halo_configure(gp, sp, gb, sb_)
+        self.segs, n_send, n_recv = plan.segments()
+        self.send, self.recv = transport.allocate(n_send, n_recv)
+
+    def exchange(self):
+        if not self.plan.peers:
+            return
+        self.engine.halo_pack(self.transport.pointer(self.send))
+        self.transport.exchange(self.send, self.recv, self.segs, self.engine)
+        self.engine.halo_unpack(self.transport.pointer(self.recv))
+
+    def step(self, n):
+        k = self.plan.depth
+        if not self.plan.peers or k <= 0:
+            self.engine.step(n)
+            return
+        while n > 0:
+            m = min(n, k - self.since)
+            self.engine.step(m)
+            self.since += m
+            n -= m
+            if self.since == k:
+                self.exchange()
+                self.since = 0
+
+
+class TorchTransport:
+    """Neighbour exchange over torch.distributed.  On GPU the P2P ops are issued while the
+    engine's own HIP stream is torch's current stream, so RCCL waits for the pack kernel and the
+    unpack kernel waits for RCCL, all device-side: no host synchronisation per exchange."""
+
+    def __init__(self, torch, dist, device, stream_ptr=None):
+        self.torch, self.dist, self.device = torch, dist, device
+        self.stream = None
+        if stream_ptr is not None and device.type == "cuda":
+            self.stream = torch.cuda.ExternalStream(stream_ptr, device=device)
+
+    def allocate(self, n_send, n_recv):
+        t = self.torch
+        return (t.zeros(max(n_send, 1), dtype=t.float32, device=self.device),
+                t.zeros(max(n_recv, 1), dtype=t.float32, device=self.device))
+
+    def pointer(self, tensor):
+        return tensor.data_ptr()
+
+    def exchange(self, send, recv, segs, engine):
+        dist = self.dist
+        ops = []
+        for s in segs:
+            for off, n in s["send"]:
+                if n:
+                    ops.append(dist.P2POp(dist.isend, send[off:off + n], s["rank"]))
+            for off, n in s["recv"]:
+                if n:
+                    ops.append(dist.P2POp(dist.irecv, recv[off:off + n], s["rank"]))
+        if not ops:
+            return
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+        else:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+
+def gather_owned(plan, buf):
+    """(global particle ids, particle rows, global beam keys, beam records) of what this rank owns."""
+    op, ob = plan.owned_particles, plan.owned_beams
+    return (plan.global_particle_id[op], buf.particles[op], plan.global_beam_key[ob], buf.beams[ob])

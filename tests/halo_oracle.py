@@ -1,0 +1,113 @@
+"""Test doubles for the multi-rank path: an oracle-backed rank engine with the halo_* methods of
+sb.Engine (TEST INFRASTRUCTURE: the product never imports this), and an in-process transport that
+wires several simulated ranks together."""
+import numpy as np
+
+
+class OracleRank:
+    """oracle.OracleEngine + halo_configure/pack/unpack on numpy buffers (what sb_halo_* do on the GPU)."""
+
+    def __init__(self, oracle, buf, bounds, mode=0, threads=1):
+        self.ref = oracle.OracleEngine(bounds, 10.0, 64, buf.layout, mode, threads=threads)
+        self.ref.write_buffers(buf)
+
+    def step(self, n):
+        self.ref.step(n)
+
+    def halo_configure(self, gp, sp, gb, sb_):
+        self.gp, self.sp, self.gb, self.sb = [np.asarray(x, dtype=np.int64) for x in (gp, sp, gb, sb_)]
+
+    def _cur(self):
+        return self.ref.particles_b if self.ref.final_in_b else self.ref.particles_a
+
+    def halo_pack(self, dst):
+        dst = np.asarray(dst)
+        n = self.sp.size
+        dst[:6 * n] = self._cur()[self.sp].reshape(-1)
+        b = self.ref.beams
+        dst[6 * n:6 * n + 2 * self.sb.size] = np.stack([b["target_length"][self.sb], b["last_length"][self.sb]], 1).reshape(-1)
+
+    def halo_unpack(self, src):
+        src = np.asarray(src)
+        n = self.gp.size
+        self._cur()[self.gp] = src[:6 * n].reshape(-1, 6)
+        tl = src[6 * n:6 * n + 2 * self.gb.size].reshape(-1, 2)
+        self.ref.beams["target_length"][self.gb] = tl[:, 0]
+        self.ref.beams["last_length"][self.gb] = tl[:, 1]
+
+    def load(self, buf):
+        return self.ref.load_buffers(buf.copy())
+
+
+class CpuTorchTransport:
+    """halo.TorchTransport for CPU tensors whose `pointer` is a numpy view (gloo tests)."""
+
+    def __init__(self, torch, dist):
+        from importlib import import_module
+        self.inner = import_module("softbody_webgpu_amd.halo").TorchTransport(torch, dist, torch.device("cpu"))
+
+    def allocate(self, a, b):
+        return self.inner.allocate(a, b)
+
+    def pointer(self, t):
+        return t.numpy()
+
+    def exchange(self, send, recv, segs, engine):
+        self.inner.exchange(send, recv, segs, engine)
+
+
+class LocalBus:
+    """Lock-step exchange between simulated ranks living in one process."""
+
+    def __init__(self):
+        self.ranks = {}
+
+    def transport(self, rank, make_buffers, pointer, sync=None):
+        bus = self
+
+        class T:
+            def allocate(self, n_send, n_recv):
+                s, r = make_buffers(n_send, n_recv)
+                bus.ranks[rank] = dict(send=s, recv=r)
+                return s, r
+
+            def pointer(self, t):
+                return pointer(t)
+
+            def exchange(self, send, recv, segs, engine):
+                bus.ranks[rank]["segs"] = segs  # the copy happens in LocalBus.flush once every rank packed
+
+        return T()
+
+    def flush(self, copy):
+        """copy(dst_tensor_slice, src_tensor_slice) for every (sender -> receiver) segment pair."""
+        for r, me in self.ranks.items():
+            for seg in me.get("segs", []):
+                peer = self.ranks[seg["rank"]]
+                back = [s for s in peer["segs"] if s["rank"] == r][0]
+                for (so, sn), (ro, rn) in zip(back["send"], seg["recv"]):
+                    assert sn == rn, "send/recv segment sizes disagree"
+                    if rn:
+                        copy(me["recv"][ro:ro + rn], peer["send"][so:so + sn])
+
+
+def step_all(exchangers, bus, n, copy, sync=lambda: None):
+    """Advance every simulated rank n substeps, exchanging ghost zones every `depth` substeps."""
+    k = exchangers[0].plan.depth
+    since = 0
+    while n > 0:
+        m = min(n, k - since) if k > 0 else n
+        for ex in exchangers:
+            ex.engine.step(m)
+        since += m
+        n -= m
+        if k > 0 and since == k:
+            for ex in exchangers:
+                ex.engine.halo_pack(ex.transport.pointer(ex.send))
+                ex.transport.exchange(ex.send, ex.recv, ex.segs, ex.engine)
+            sync()
+            bus.flush(copy)
+            sync()
+            for ex in exchangers:
+                ex.engine.halo_unpack(ex.transport.pointer(ex.recv))
+            since = 0
