@@ -142,10 +142,11 @@ def main():
         stepper = halo.Exchanger(eng, plan, transport).step
 
     def barrier():
+        eng.sync()                 # the engine runs on its own HIP stream
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        eng.sync()
+            torch.cuda.synchronize()
 
     stepper(a.warmup)
     barrier()
