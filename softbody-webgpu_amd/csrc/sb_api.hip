@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <unordered_map>
 
 #include "sb_engine.h"
 
@@ -299,11 +300,11 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
 
     // ---- beam copies
     std::vector<uint32_t> c_ia, c_ib, c_pair, c_slot;
+    std::vector<float> mat_table;
     e->h_copy_of_slot.assign(B, 0);
     if (e->path == SB_PATH_TILED) {
         e->ntiles = tl.ntiles;
         e->nhalo = (uint32_t)tl.halo_idx.size();
-        c_pair = tl.copy_pair;
         c_slot = tl.copy_slot;
         e->h_copy_of_slot = tl.copy_of_slot;
         e->tile_cap_own = tl.max_own;
@@ -317,9 +318,53 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         SB_HIP(e, hipMemcpy(e->d_tile_h0, tl.tile_h0.data(), tl.tile_h0.size() * 4, hipMemcpyHostToDevice));
         if (!tl.halo_idx.empty())
             SB_HIP(e, hipMemcpy(e->d_halo_idx, tl.halo_idx.data(), tl.halo_idx.size() * 4, hipMemcpyHostToDevice));
-        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_own * sizeof(int2);
         if (tl.max_all > 65535)
             SB_FAIL(e, SB_ERR_UNSUPPORTED, "a tile addresses %u particles (> 65535, 16-bit local indices): lower tile_particles", tl.max_all);
+        // ---- material dictionary: beams that share (length, spring, damp, yield, limit) share one
+        // table row, and the row number rides in the spare bits of the endpoint word.  Lossless;
+        // falls back to (spring, damp, yield, limit) rows + per-copy length, then to per-copy arrays.
+        uint32_t lbits = 1;
+        while ((1u << lbits) <= tl.max_all) lbits++; // all-ones local index stays free for the dead marker
+        const uint32_t mbits = lbits >= 16 ? 0 : 32 - 2 * lbits;
+        const uint32_t mat_cap = mbits == 0 ? 0 : std::min<uint32_t>(1u << std::min(mbits, 12u), 2048u);
+        struct Key { uint32_t w[5]; bool operator==(const Key &o) const { return memcmp(w, o.w, sizeof w) == 0; } };
+        struct KeyHash { size_t operator()(const Key &k) const { size_t h = 1469598103934665603ull; for (uint32_t x : k.w) h = (h ^ x) * 1099511628211ull; return h; } };
+        std::vector<uint32_t> mat_of_slot(B, 0);
+        e->mat_mode = 0;
+        for (int mode = 2; mode >= 1 && mat_cap; mode--) {
+            std::unordered_map<Key, uint32_t, KeyHash> dict;
+            std::vector<float> table;
+            bool ok = true;
+            for (uint32_t s = 0; s < B && ok; s++) {
+                Key k;
+                const float *f = hb[s].f; // length, target, last, spring, damp, yield, limit
+                float row[5] = {mode == 2 ? f[0] : 0.0f, f[3], f[4], f[5], f[6]};
+                memcpy(k.w, row, sizeof row);
+                auto it = dict.find(k);
+                if (it == dict.end()) {
+                    if (dict.size() >= mat_cap) { ok = false; break; }
+                    it = dict.emplace(k, (uint32_t)dict.size()).first;
+                    table.insert(table.end(), row, row + 5);
+                }
+                mat_of_slot[s] = it->second;
+            }
+            if (ok) {
+                e->mat_mode = (uint32_t)mode;
+                mat_table.swap(table);
+                break;
+            }
+        }
+        if (e->mat_mode == 0) lbits = 16;
+        e->lbits = lbits;
+        e->nmat = (uint32_t)(mat_table.size() / 5);
+        c_pair.assign(tl.copy_la.size(), 0xFFFFFFFFu);
+        for (size_t c = 0; c < c_pair.size(); c++) {
+            if (tl.copy_slot[c] == 0xFFFFFFFFu) continue;
+            uint32_t w = tl.copy_la[c] | (tl.copy_lb[c] << lbits);
+            if (e->mat_mode) w |= mat_of_slot[tl.copy_slot[c]] << (2 * lbits);
+            c_pair[c] = w;
+        }
+        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_own * sizeof(int2) + (size_t)e->nmat * 5 * sizeof(float);
         if (e->lds_bytes > 160 * 1024)
             SB_FAIL(e, SB_ERR_UNSUPPORTED, "tile needs %zu bytes of LDS (> 160 KiB): lower tile_particles or use SB_PATH_ATOMIC", e->lds_bytes);
     } else {
@@ -341,6 +386,12 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
                                            &SbBeamArrays::limit,  &SbBeamArrays::strain, &SbBeamArrays::stress};
         std::vector<float> tmp(nc);
         for (int k = 0; k < 9; k++) {
+            // the material table replaces the static parameter arrays (and the length array in mode 2)
+            const bool is_static = k == 0 || (k >= 3 && k <= 6);
+            if (e->path == SB_PATH_TILED && is_static && (e->mat_mode == 2 || (e->mat_mode == 1 && k != 0))) {
+                e->beams.*fields[k] = nullptr;
+                continue;
+            }
             for (uint32_t c = 0; c < nc; c++) tmp[c] = c_slot[c] == 0xFFFFFFFFu ? 0.0f : hb[c_slot[c]].f[k];
             SB_TRY(dev_alloc(e, &(e->beams.*fields[k]), nc));
             if (nc) SB_HIP(e, hipMemcpy(e->beams.*fields[k], tmp.data(), nc * 4, hipMemcpyHostToDevice));
@@ -350,6 +401,9 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         if (e->path == SB_PATH_TILED) {
             SB_TRY(dev_alloc(e, &e->beams.pair, nc));
             if (nc) SB_HIP(e, hipMemcpy(e->beams.pair, c_pair.data(), nc * 4, hipMemcpyHostToDevice));
+            SB_TRY(dev_alloc(e, &e->d_mat, mat_table.size()));
+            if (!mat_table.empty())
+                SB_HIP(e, hipMemcpy(e->d_mat, mat_table.data(), mat_table.size() * 4, hipMemcpyHostToDevice));
         } else {
             SB_TRY(dev_alloc(e, &e->beams.ia, nc));
             SB_TRY(dev_alloc(e, &e->beams.ib, nc));
@@ -450,7 +504,9 @@ sb_status sb_step(sb_engine *e, uint32_t n)
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
-    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e);
+    // strain/stress are pure outputs (render inputs in the reference, render.wgsl:82): only the
+    // last substep before control returns to the caller can ever be observed, so only it stores them
+    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
     SB_HIP(e, hipGetLastError());
     return SB_OK;
 }
@@ -486,7 +542,7 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step_timed before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipEventRecord(e->ev0, e->stream));
-    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e);
+    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
     SB_HIP(e, hipGetLastError());
     SB_HIP(e, hipEventRecord(e->ev1, e->stream));
     SB_HIP(e, hipEventSynchronize(e->ev1));
@@ -628,6 +684,9 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "kernels_per_substep")
         *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 5 : 0);
     else if (k == "grid_cells") *value = e->ncell;
+    else if (k == "material_mode") *value = e->mat_mode;
+    else if (k == "materials") *value = e->nmat;
+    else if (k == "local_index_bits") *value = e->lbits;
     else SB_FAIL(e, SB_ERR_INVALID, "sb_get_info: unknown key '%s'", key);
     return SB_OK;
 }

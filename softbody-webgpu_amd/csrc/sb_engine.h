@@ -15,7 +15,7 @@
 // cut by a tile boundary appears once in each of its two tiles (DESIGN.md "cut beams").
 struct SbBeamArrays {
     uint32_t *ia, *ib;  // atomic path: internal particle indices of the endpoints
-    uint32_t *pair;     // tiled path: lo16 = tile-local index of A, hi16 = of B; 0xFFFFFFFF = dead
+    uint32_t *pair;     // tiled path: local A | local B << lbits | material << 2*lbits; 0xFFFFFFFF = dead
     float *length, *target, *last, *spring, *damp, *yield, *limit, *strain, *stress;
     uint32_t *slot;     // beam mapping slot (as of upload) this copy belongs to
 };
@@ -75,6 +75,12 @@ struct sb_engine {
     uint32_t *d_tile_h0 = nullptr;    // [ntiles+1] first halo entry of each tile
     uint32_t *d_halo_idx = nullptr;   // internal particle index of each halo entry
     size_t lds_bytes = 0;
+    // beam word packing and material dictionary (tiled path)
+    uint32_t lbits = 16;      // bits per tile-local endpoint index
+    uint32_t mat_mode = 0;    // 0: per-copy parameter arrays; 1: table of (spring,damp,yield,limit) + per-copy length;
+                              // 2: table of (length,spring,damp,yield,limit)
+    uint32_t nmat = 0;
+    float *d_mat = nullptr;   // [nmat][5] = length, spring, damp, yield_strain, strain_break_limit
 
     // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state every substep
     SbGrid grid{};
@@ -89,7 +95,7 @@ struct sb_engine {
 };
 
 // sb_kernels.hip
-void sbk_launch_substep(sb_engine *e);
+void sbk_launch_substep(sb_engine *e, bool write_aux);
 void sbk_launch_delete(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float *src);

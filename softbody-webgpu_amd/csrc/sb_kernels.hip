@@ -22,7 +22,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_beams_atomic(SbBeamArrays b, uint3
     uint32_t ia = b.ia[i];
     if (ia == 0xFFFFFFFFu) return; // removed by a delete pass
     uint32_t ib = b.ib[i];
-    SbBeamResult r = sb_beam_eval(pos[ia], pos[ib], b.length[i], b.target[i], b.last[i], b.spring[i],
+    SbBeamResult r = sb_beam_eval<true>(pos[ia], pos[ib], b.length[i], b.target[i], b.last[i], b.spring[i],
                                   b.damp[i], b.yield[i], b.limit[i]);
     b.target[i] = r.target_length;
     b.last[i] = r.last_length;
@@ -110,17 +110,18 @@ SB_DEV uint32_t sb_tile_of_block(uint32_t b, uint32_t n)
 // HBM traffic per substep = beam slice (36 B read + 16 B written per copy) + particles
 // (24 B read + 24 B written) + halo positions (8 B each, mostly L2 hits): the force
 // accumulator (compute.wgsl:68-69) never leaves the CU.
-template <int MODE>
+template <int MODE, int MAT, bool AUX>
 __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
-    const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all,
-    const SbConsts *__restrict__ cp, SbParams prm, uint32_t *broken, const uint32_t *__restrict__ pidx,
-    SbGrid grid)
+    const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits,
+    const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts *__restrict__ cp, SbParams prm,
+    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
     int *s_f = (int *)(s_pos + cap_all);
+    float *s_mat = (float *)(s_f + 2 * cap_own);
 
     const uint32_t tile = sb_tile_of_block(blockIdx.x, ntiles);
     const uint32_t p0 = tile_p0[tile], n_own = tile_p0[tile + 1] - p0;
@@ -134,20 +135,41 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         s_f[2 * i + 1] = 0;
     }
     for (uint32_t i = tid; i < n_halo; i += SB_BLOCK) s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
+    if (MAT != 0)
+        for (uint32_t i = tid; i < nmat * 5u; i += SB_BLOCK) s_mat[i] = mat_tab[i];
     __syncthreads();
 
+    const uint32_t lmask = (1u << lbits) - 1u;
 #pragma unroll 2
     for (uint32_t j = tid; j < nb; j += SB_BLOCK) {
         const uint32_t c = b0 + j;
-        const uint32_t pair = b.pair[c];
-        if (pair == 0xFFFFFFFFu) continue; // padding or removed by a delete pass
-        const uint32_t la = pair & 0xffffu, lb = pair >> 16;
-        SbBeamResult res = sb_beam_eval(s_pos[la], s_pos[lb], b.length[c], b.target[c], b.last[c],
-                                        b.spring[c], b.damp[c], b.yield[c], b.limit[c]);
-        b.target[c] = res.target_length;
+        const uint32_t word = b.pair[c];
+        if (word == 0xFFFFFFFFu) continue; // padding or removed by a delete pass
+        const uint32_t la = word & lmask, lb = (word >> lbits) & lmask;
+        float length, spring, damp, yield, limit;
+        if (MAT != 0) {
+            const float *m = s_mat + 5u * (word >> (2u * lbits));
+            length = MAT == 2 ? m[0] : b.length[c];
+            spring = m[1];
+            damp = m[2];
+            yield = m[3];
+            limit = m[4];
+        } else {
+            length = b.length[c];
+            spring = b.spring[c];
+            damp = b.damp[c];
+            yield = b.yield[c];
+            limit = b.limit[c];
+        }
+        const float target = b.target[c];
+        SbBeamResult res = sb_beam_eval<AUX>(s_pos[la], s_pos[lb], length, target, b.last[c], spring, damp, yield, limit);
+        // target_length only moves on plastic yield (compute.wgsl:113-116): store it when it did
+        if (__float_as_uint(res.target_length) != __float_as_uint(target)) b.target[c] = res.target_length;
         b.last[c] = res.last_length;
-        b.strain[c] = res.strain;
-        b.stress[c] = res.stress;
+        if (AUX) { // strain/stress: outputs only (compute.wgsl:122-123), stored by the last substep of a call
+            b.strain[c] = res.strain;
+            b.stress[c] = res.stress;
+        }
         if (la < n_own) {
             atomicAdd(&s_f[2 * la], res.ax);
             atomicAdd(&s_f[2 * la + 1], res.ay);
@@ -177,7 +199,6 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         w.acc[g] = particle.a;
     }
 }
-
 
 // ---------------------------------------------------------------- spatial hash build
 
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, Sb
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-void sbk_launch_substep(sb_engine *e)
+void sbk_launch_substep(sb_engine *e, bool write_aux)
 {
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
     const uint32_t mode = e->opt.collision_mode;
@@ -362,11 +383,15 @@ void sbk_launch_substep(sb_engine *e)
 #undef SB_LAUNCH_P
         }
     } else if (e->ntiles) {
-#define SB_LAUNCH_T(M) k_substep_tiled<M><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(                      \
+#define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
-        e->d_consts, e->prm, e->d_broken, e->d_pidx, e->grid)
-        if (mode == SB_COLLIDE_GRID) SB_LAUNCH_T(SB_COLLIDE_GRID);
-        else SB_LAUNCH_T(SB_COLLIDE_OFF);
+        e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->d_consts, e->prm, e->d_broken, e->d_pidx, e->grid)
+#define SB_LAUNCH_TA(M, T) do { if (write_aux) SB_LAUNCH_T(M, T, true); else SB_LAUNCH_T(M, T, false); } while (0)
+#define SB_LAUNCH_TM(M) do { if (e->mat_mode == 2) SB_LAUNCH_TA(M, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(M, 1); else SB_LAUNCH_TA(M, 0); } while (0)
+        if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(SB_COLLIDE_GRID);
+        else SB_LAUNCH_TM(SB_COLLIDE_OFF);
+#undef SB_LAUNCH_TM
+#undef SB_LAUNCH_TA
 #undef SB_LAUNCH_T
     }
     e->cur ^= 1;

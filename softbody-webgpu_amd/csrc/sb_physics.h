@@ -40,13 +40,14 @@ SB_DEV float sb_sqrt(float x) { return __builtin_sqrtf(x); }
 SB_DEV float sb_div(float a, float b) { return a / b; }
 SB_DEV float sb_length(float x, float y) { return sb_sqrt(x * x + y * y); }
 
-// i32(f): truncate toward zero, saturating, NaN -> 0 (compute.wgsl:127-130)
+// i32(f): truncate toward zero, saturating, NaN -> 0 (compute.wgsl:127-130).  That is exactly what
+// one v_cvt_i32_f32 does on gfx950 (out-of-range clamps to INT_MIN/INT_MAX, NaN gives 0); spelled as
+// inline asm so neither a chain of range checks nor a UB-exploiting fold of `(int)x` can appear.
 SB_DEV int32_t sb_f32_to_i32(float x)
 {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return INT32_MAX;
-    if (x <= -2147483648.0f) return INT32_MIN;
-    return (int32_t)x;
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // pow for the drag term (compute.wgsl:175).  Exact products for exponents 1..4, otherwise
@@ -132,6 +133,12 @@ struct SbBeamResult {
     bool broken;            // mark_beam_deleted condition (:117)
 };
 
+// AUX = also produce strain/stress (compute.wgsl:122-123: outputs nobody reads before the caller
+// gets control back).  Without AUX the strain division is only executed for beams close to or
+// past their yield point: |len-target| <= 0.999*yield*length implies fl((len-target)/length) <= yield
+// for every input (the filter is conservative; NaN/inf/zero parameters fall through to the exact
+// path or agree with it), so the yield decision is bit-identical to evaluating :112-113 as written.
+template <bool AUX>
 SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float target_length,
                                  float last_length, float spring, float damp, float yield_strain,
                                  float strain_break_limit)
@@ -140,26 +147,35 @@ SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float targe
     const float beam_stress_scale = 1.0f / 20.0f; // :71
     SbBeamResult r;
     float dx = pb.x - pa.x, dy = pb.y - pa.y; // :103
-    if (sb_length(dx, dy) == 0.0f) {          // :104-107
+    float len = sb_length(dx, dy);            // :104 / :108 (same value unless the guard fires)
+    if (len == 0.0f) {                        // :104-107
         dx = 0.0f;
         dy = -1.0e-10f;
+        len = sb_length(0.0f, -1.0e-10f);     // folded at compile time, correctly rounded
     }
-    float len = sb_length(dx, dy);            // :108
     float force_mag = (target_length - len) * spring + (last_length - len) * damp; // :110
     float nx = sb_div(dx, len), ny = sb_div(dy, len); // normalize(diff)
     float fx = force_mag * nx, fy = force_mag * ny;   // :111
-    float strain = sb_div(len - target_length, length); // :112
-    if (sb_abs(strain) > yield_strain)                  // :113-116
-        target_length = len - yield_strain * length * sb_sign(strain);
-    r.broken = sb_abs(len - length) > length * strain_break_limit; // :117
-    r.stress = force_mag * beam_stress_scale;                      // :122
-    r.strain = sb_div(sb_abs(strain), yield_strain);               // :123
-    r.last_length = len;                                           // :124
+    const float stretch = len - target_length;
     r.target_length = target_length;
-    r.ax = sb_f32_to_i32(-fx * particle_force_scale); // :127
-    r.ay = sb_f32_to_i32(-fy * particle_force_scale); // :128
-    r.bx = sb_f32_to_i32(fx * particle_force_scale);  // :129
-    r.by = sb_f32_to_i32(fy * particle_force_scale);  // :130
+    r.strain = 0.0f;
+    r.stress = 0.0f;
+    if (AUX || sb_abs(stretch) > yield_strain * length * 0.999f) {
+        float strain = sb_div(stretch, length);  // :112
+        if (sb_abs(strain) > yield_strain)       // :113-116
+            r.target_length = len - yield_strain * length * sb_sign(strain);
+        if (AUX) {
+            r.stress = force_mag * beam_stress_scale;        // :122
+            r.strain = sb_div(sb_abs(strain), yield_strain); // :123
+        }
+    }
+    r.broken = sb_abs(len - length) > length * strain_break_limit; // :117
+    r.last_length = len;                                           // :124
+    const float sx = fx * particle_force_scale, sy = fy * particle_force_scale;
+    r.bx = sb_f32_to_i32(sx);  // :129
+    r.by = sb_f32_to_i32(sy);  // :130
+    r.ax = sb_f32_to_i32(-sx); // :127  (-f*s == -(f*s) exactly)
+    r.ay = sb_f32_to_i32(-sy); // :128
     return r;
 }
 

@@ -28,7 +28,7 @@ struct SbTiling {
     std::vector<uint32_t> tile_b0;      // [ntiles+1] beam-copy ranges (padded to x4 with dead copies)
     std::vector<uint32_t> tile_h0;      // [ntiles+1] halo ranges
     std::vector<uint32_t> halo_idx;     // internal particle index of each halo entry
-    std::vector<uint32_t> copy_pair;    // lo16 local A | hi16 local B; 0xFFFFFFFF = padding
+    std::vector<uint32_t> copy_la, copy_lb; // tile-local endpoint indices; 0xFFFFFFFF = padding
     std::vector<uint32_t> copy_slot;    // beam slot of each copy; 0xFFFFFFFF = padding
     std::vector<uint32_t> copy_of_slot; // beam slot -> the copy in the tile that owns endpoint A
     uint32_t max_own = 0, max_all = 0;
@@ -129,7 +129,8 @@ inline void sb_build_tiling(SbTiling &t, const std::vector<float> &px, const std
 
     // pass 2: emit copies in slot order inside each tile
     const uint32_t total = t.tile_b0[t.ntiles];
-    t.copy_pair.assign(total, 0xFFFFFFFFu);
+    t.copy_la.assign(total, 0xFFFFFFFFu);
+    t.copy_lb.assign(total, 0xFFFFFFFFu);
     t.copy_slot.assign(total, 0xFFFFFFFFu);
     t.copy_of_slot.assign(B, 0);
     std::vector<uint32_t> cursor(t.tile_b0.begin(), t.tile_b0.end() - 1);
@@ -143,12 +144,14 @@ inline void sb_build_tiling(SbTiling &t, const std::vector<float> &px, const std
         uint32_t ia = internal_of_slot[beams[s].a], ib = internal_of_slot[beams[s].b];
         uint32_t ta = tile_of[ia], tb = tile_of[ib];
         uint32_t c = cursor[ta]++;
-        t.copy_pair[c] = local(ta, ia) | (local(ta, ib) << 16);
+        t.copy_la[c] = local(ta, ia);
+        t.copy_lb[c] = local(ta, ib);
         t.copy_slot[c] = s;
         t.copy_of_slot[s] = c;
         if (tb != ta) {
             uint32_t d = cursor[tb]++;
-            t.copy_pair[d] = local(tb, ia) | (local(tb, ib) << 16);
+            t.copy_la[d] = local(tb, ia);
+            t.copy_lb[d] = local(tb, ib);
             t.copy_slot[d] = s;
         }
     }

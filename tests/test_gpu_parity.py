@@ -243,3 +243,51 @@ def test_grid_two_blobs_and_rain(sb, oracle, path):
     assert_same(got, exp, "two blobs path %d" % path)
     off, _, _ = run_both(sb, oracle, buf, n=256, mode=OFF, path=path, bounds=4000.0, tile=256)
     assert (off.particles != got.particles).any(axis=1).sum() > 1000  # collisions really acted
+
+
+# ---------------------------------------------------------------- material dictionary fallbacks
+
+@pytest.mark.parametrize("vary,expect_mode", [("none", 2), ("length", 1), ("spring", 0)])
+def test_material_dictionary_modes(sb, oracle, vary, expect_mode):
+    """The tiled kernel dictionary-encodes the static beam parameters (lossless).  Force each of
+    its three encodings -- full rows, rows without length, plain per-copy arrays -- and check
+    bit-exact parity in all of them."""
+    buf = sb.scenes.lattice_buffers(48, 48, d=25.0, origin=(100.0, 100.0), jitter=2.0, layout=2, strain_limit=0.5)
+    B = buf.beam_count
+    rng = np.random.default_rng(17)
+    if vary == "length":   # every beam its own rest length (like an editor-triangulated scene)
+        L = (buf.beams["length"][:B] * rng.uniform(0.97, 1.03, B)).astype("f4")
+        buf.beams["length"][:B] = L
+        buf.beams["target_length"][:B] = L
+        buf.beams["last_length"][:B] = L
+    if vary == "spring":
+        buf.beams["spring"][:B] = rng.uniform(20, 60, B).astype("f4")
+    eng = sb.Engine(bounds_size=4000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                    collision_mode=OFF, path=TILED, tile_particles=256)
+    eng.write_buffers(buf)
+    assert eng.info("material_mode") == expect_mode
+    eng.destroy()
+    got, exp, _ = run_both(sb, oracle, buf, n=200, mode=OFF, path=TILED, bounds=4000.0, tile=256)
+    assert_same(got, exp, "materials vary=%s" % vary)
+
+
+def test_force_saturation_and_nonfinite(sb, oracle):
+    """i32() saturates at +-2^31 and maps NaN to 0 (compute.wgsl:127-130): on the GPU that is one
+    v_cvt_i32_f32, in the oracle explicit range checks.  Absurd spring constants push the
+    fixed-point force past both limits; one substep (before positions go non-finite) must agree."""
+    P = [[100, 100, 0, 0, 0, 0], [220, 100, 0, 0, 0, 0], [100, 300, 0, 0, 0, 0], [100, 420, 0, 0, 0, 0],
+         [400, 400, 0, 0, 0, 0], [400, 400, 0, 0, 0, 0]]
+    buf = sb.Buffers(2, 8, 8)
+    bb = np.zeros(3, sb.layout.BEAM_DTYPE[2])
+    # stretched by 20: force = -20*1e9 -> -2e10*65536 saturates; second beam compressed; third zero-length
+    bb[0] = (0, 1, 100, 100, 100, 1e9, 0, 5, 50, 0, 0)
+    bb[1] = (2, 3, 140, 140, 140, 3e8, 0, 5, 50, 0, 0)
+    bb[2] = (4, 5, 50, 50, 50, 1e30, 0, 5, 50, 0, 0)
+    buf.set_scene(np.array(P, "f4"), bb)
+    buf.set_physics_constants(gravity=(0.0, 0.0), border_elasticity=0.5, border_friction=0.2, elasticity=0.5,
+                              friction=0.1, drag_coeff=0.0, drag_exp=2.0)
+    for path in (ATOMIC, TILED):
+        got, exp, _ = run_both(sb, oracle, buf, n=1, mode=OFF, path=path, tile=64)
+        assert_same(got, exp, "saturation path %d" % path)
+        v = exp.particles[:4, 2:4]
+        assert np.abs(v).max() == np.float32(32768.0 / 64.0)  # (2^31 / 65536) * dt: the saturated force
