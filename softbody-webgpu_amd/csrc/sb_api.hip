@@ -316,6 +316,11 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         SB_HIP(e, hipMemcpy(e->d_tile_p0, tl.tile_p0.data(), tl.tile_p0.size() * 4, hipMemcpyHostToDevice));
         SB_HIP(e, hipMemcpy(e->d_tile_b0, tl.tile_b0.data(), tl.tile_b0.size() * 4, hipMemcpyHostToDevice));
         SB_HIP(e, hipMemcpy(e->d_tile_h0, tl.tile_h0.data(), tl.tile_h0.size() * 4, hipMemcpyHostToDevice));
+        // buffer A holds whatever accelerations were uploaded; buffer B is all zeros (engineWorker.ts:593)
+        SB_TRY(dev_alloc(e, &e->d_acc_flag[0], tl.ntiles));
+        SB_TRY(dev_alloc(e, &e->d_acc_flag[1], tl.ntiles));
+        SB_HIP(e, hipMemset(e->d_acc_flag[0], 0x01, std::max<size_t>(tl.ntiles, 1) * 4));
+        SB_HIP(e, hipMemset(e->d_acc_flag[1], 0x00, std::max<size_t>(tl.ntiles, 1) * 4));
         if (!tl.halo_idx.empty())
             SB_HIP(e, hipMemcpy(e->d_halo_idx, tl.halo_idx.data(), tl.halo_idx.size() * 4, hipMemcpyHostToDevice));
         if (tl.max_all > 65535)

@@ -75,6 +75,7 @@ struct sb_engine {
     uint32_t *d_tile_h0 = nullptr;    // [ntiles+1] first halo entry of each tile
     uint32_t *d_halo_idx = nullptr;   // internal particle index of each halo entry
     size_t lds_bytes = 0;
+    uint32_t *d_acc_flag[2] = {nullptr, nullptr}; // per particle buffer, per tile: 0 = every acc is zero
     // beam word packing and material dictionary (tiled path)
     uint32_t lbits = 16;      // bits per tile-local endpoint index
     uint32_t mat_mode = 0;    // 0: per-copy parameter arrays; 1: table of (spring,damp,yield,limit) + per-copy length;

@@ -10,6 +10,10 @@
 #include "sb_engine.h"
 
 #define SB_BLOCK 256
+#ifndef SB_ABLATE
+#define SB_ABLATE 0
+#endif
+#define SB_UNROLL 4
 
 // ---------------------------------------------------------------- SB_PATH_ATOMIC
 
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
     const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits,
     const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts *__restrict__ cp, SbParams prm,
-    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid)
+    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid, const uint32_t *__restrict__ acc_flag_r,
+    uint32_t *acc_flag_w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
@@ -129,75 +134,171 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     const uint32_t b0 = tile_b0[tile], nb = tile_b0[tile + 1] - b0;
     const uint32_t tid = threadIdx.x;
 
-    for (uint32_t i = tid; i < n_own; i += SB_BLOCK) {
+    // Phase 0.  Everything this workgroup will ever read from the particle arrays is requested
+    // up front, back to back: the halo indices, the owned positions, and (for phase 2) the owned
+    // velocities and accelerations of the first SB_UNROLL x 256 particles.  The dependent halo
+    // position gather goes out as soon as its indices are back.
+    // acc_flag[buffer][tile] == 0 guarantees that every acceleration of the tile in that buffer IS
+    // zero (true for almost every tile: compute.wgsl:188 zeroes a, only border friction :192,:196
+    // sets it), so the 8 B/particle read and the 8 B/particle write of zeros can both be skipped.
+    const bool acc_r = acc_flag_r[tile] != 0u, acc_w_dirty = acc_flag_w[tile] != 0u;
+    uint32_t hidx = 0;
+    const bool has_halo = tid < n_halo;
+    if (has_halo) hidx = halo_idx[h0 + tid];
+    float2 pp[SB_UNROLL], pv[SB_UNROLL], pa[SB_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SB_UNROLL; u++) {
+        const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+        if (i < n_own) {
+            pp[u] = r.pos[p0 + i];
+            pv[u] = r.vel[p0 + i];
+            pa[u] = acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f);
+        }
+    }
+    float2 hp = make_float2(0.f, 0.f);
+    if (has_halo) hp = r.pos[hidx];
+#pragma unroll
+    for (int u = 0; u < SB_UNROLL; u++) {
+        const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+        if (i < n_own) {
+            s_pos[i] = pp[u];
+            s_f[2 * i] = 0;
+            s_f[2 * i + 1] = 0;
+        }
+    }
+    for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK) { // tiles above 1024 particles
         s_pos[i] = r.pos[p0 + i];
         s_f[2 * i] = 0;
         s_f[2 * i + 1] = 0;
     }
-    for (uint32_t i = tid; i < n_halo; i += SB_BLOCK) s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
+    if (has_halo) s_pos[n_own + tid] = hp;
+    for (uint32_t i = tid + SB_BLOCK; i < n_halo; i += SB_BLOCK) s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
     if (MAT != 0)
         for (uint32_t i = tid; i < nmat * 5u; i += SB_BLOCK) s_mat[i] = mat_tab[i];
     __syncthreads();
 
+    // Beam phase.  The slice is walked in batches of SB_UNROLL x 256 copies: all global loads of a
+    // batch are issued back to back (and the next batch's before this one is evaluated), so a wave
+    // keeps ~2 x 3 x SB_UNROLL loads in flight instead of paying two dependent HBM latencies per beam.
     const uint32_t lmask = (1u << lbits) - 1u;
-#pragma unroll 2
-    for (uint32_t j = tid; j < nb; j += SB_BLOCK) {
-        const uint32_t c = b0 + j;
-        const uint32_t word = b.pair[c];
-        if (word == 0xFFFFFFFFu) continue; // padding or removed by a delete pass
-        const uint32_t la = word & lmask, lb = (word >> lbits) & lmask;
-        float length, spring, damp, yield, limit;
-        if (MAT != 0) {
-            const float *m = s_mat + 5u * (word >> (2u * lbits));
-            length = MAT == 2 ? m[0] : b.length[c];
-            spring = m[1];
-            damp = m[2];
-            yield = m[3];
-            limit = m[4];
-        } else {
-            length = b.length[c];
-            spring = b.spring[c];
-            damp = b.damp[c];
-            yield = b.yield[c];
-            limit = b.limit[c];
+    uint32_t wd[SB_UNROLL], wn[SB_UNROLL];
+    float tg[SB_UNROLL], ls[SB_UNROLL], ln[SB_UNROLL], tgn[SB_UNROLL], lsn[SB_UNROLL], lnn[SB_UNROLL];
+    auto fetch = [&](uint32_t j0, uint32_t *wo, float *to, float *lo, float *leno) {
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; u++) {
+            const uint32_t j = j0 + (uint32_t)u * SB_BLOCK;
+            const bool ok = j < nb;
+            const uint32_t cidx = b0 + (ok ? j : 0u);
+            wo[u] = ok ? b.pair[cidx] : 0xFFFFFFFFu;
+            to[u] = b.target[cidx];
+            lo[u] = b.last[cidx];
+            leno[u] = (MAT != 2) ? b.length[cidx] : 0.0f;
         }
-        const float target = b.target[c];
-        SbBeamResult res = sb_beam_eval<AUX>(s_pos[la], s_pos[lb], length, target, b.last[c], spring, damp, yield, limit);
-        // target_length only moves on plastic yield (compute.wgsl:113-116): store it when it did
-        if (__float_as_uint(res.target_length) != __float_as_uint(target)) b.target[c] = res.target_length;
-        b.last[c] = res.last_length;
-        if (AUX) { // strain/stress: outputs only (compute.wgsl:122-123), stored by the last substep of a call
-            b.strain[c] = res.strain;
-            b.stress[c] = res.stress;
+    };
+    if (nb) fetch(tid, wd, tg, ls, ln);
+    for (uint32_t j0 = tid; j0 < nb + tid; j0 += SB_UNROLL * SB_BLOCK) {
+        const uint32_t jn = j0 + SB_UNROLL * SB_BLOCK;
+        if (jn < nb + tid) fetch(jn, wn, tgn, lsn, lnn);
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; u++) {
+            const uint32_t word = wd[u];
+            if (word != 0xFFFFFFFFu) { // padding, out of range, or removed by a delete pass
+                const uint32_t c = b0 + j0 + (uint32_t)u * SB_BLOCK;
+                const uint32_t la = word & lmask, lb = (word >> lbits) & lmask;
+                float length, spring, damp, yield, limit;
+                if (MAT != 0) {
+                    const float *m = s_mat + 5u * (word >> (2u * lbits));
+                    length = MAT == 2 ? m[0] : ln[u];
+                    spring = m[1];
+                    damp = m[2];
+                    yield = m[3];
+                    limit = m[4];
+                } else {
+                    length = ln[u];
+                    spring = b.spring[c];
+                    damp = b.damp[c];
+                    yield = b.yield[c];
+                    limit = b.limit[c];
+                }
+                const float target = tg[u];
+#if SB_ABLATE & 1 // diagnostic build: beam arithmetic replaced by a data-dependent dummy
+                SbBeamResult res;
+                {
+                    float2 qa = s_pos[la], qb = s_pos[lb];
+                    res.target_length = target;
+                    res.last_length = ls[u] + (qa.x - qb.x) * spring + length * damp + yield * limit;
+                    res.strain = res.stress = 0.f;
+                    res.ax = __float_as_int(qa.y);
+                    res.ay = __float_as_int(qb.y);
+                    res.bx = res.ax ^ 5;
+                    res.by = res.ay ^ 9;
+                    res.broken = false;
+                }
+#else
+                SbBeamResult res = sb_beam_eval<AUX>(s_pos[la], s_pos[lb], length, target, ls[u], spring, damp, yield, limit);
+#endif
+                // target_length only moves on plastic yield (compute.wgsl:113-116): store it when it did
+                if (__float_as_uint(res.target_length) != __float_as_uint(target)) b.target[c] = res.target_length;
+                b.last[c] = res.last_length;
+                if (AUX) { // strain/stress: outputs only (:122-123), stored by the last substep of a call
+                    b.strain[c] = res.strain;
+                    b.stress[c] = res.stress;
+                }
+                if (la < n_own) {
+                    atomicAdd(&s_f[2 * la], res.ax);
+                    atomicAdd(&s_f[2 * la + 1], res.ay);
+                }
+                if (lb < n_own) {
+                    atomicAdd(&s_f[2 * lb], res.bx);
+                    atomicAdd(&s_f[2 * lb + 1], res.by);
+                }
+                if (res.broken) atomicOr(&broken[c >> 5], 1u << (c & 31));
+            }
         }
-        if (la < n_own) {
-            atomicAdd(&s_f[2 * la], res.ax);
-            atomicAdd(&s_f[2 * la + 1], res.ay);
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; u++) {
+            wd[u] = wn[u];
+            tg[u] = tgn[u];
+            ls[u] = lsn[u];
+            ln[u] = lnn[u];
         }
-        if (lb < n_own) {
-            atomicAdd(&s_f[2 * lb], res.bx);
-            atomicAdd(&s_f[2 * lb + 1], res.by);
-        }
-        if (res.broken) atomicOr(&broken[c >> 5], 1u << (c & 31));
     }
     __syncthreads();
 
+    // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
     const SbConsts c = *cp;
-    for (uint32_t i = tid; i < n_own; i += SB_BLOCK) {
+    bool any_acc = false;
+    auto finish = [&](uint32_t i, float2 vel, float2 acc) {
         const uint32_t g = p0 + i;
         SbParticle particle;
         particle.p = s_pos[i];
-        particle.v = r.vel[g];
-        particle.a = r.acc[g];
+        particle.v = vel;
+        particle.a = acc;
         if (MODE == SB_COLLIDE_GRID) {
             const SbParticle self = particle; // :141
             sb_collide_grid(grid, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx, r.vel);
         }
+#if SB_ABLATE & 2 // diagnostic build: particle arithmetic replaced by a data-dependent dummy
+        particle.v.x += (float)s_f[2 * i] * prm.time_step;
+        particle.v.y += (float)s_f[2 * i + 1] * c.gravity_y;
+#else
         sb_particle_finish(prm, c, particle, s_f[2 * i], s_f[2 * i + 1]);
+#endif
         w.pos[g] = particle.p;
         w.vel[g] = particle.v;
-        w.acc[g] = particle.a;
+        const bool nz = (__float_as_uint(particle.a.x) | __float_as_uint(particle.a.y)) != 0u; // -0.0 counts
+        any_acc |= nz;
+        if (nz || acc_w_dirty) w.acc[g] = particle.a;
+    };
+#pragma unroll
+    for (int u = 0; u < SB_UNROLL; u++) {
+        const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+        if (i < n_own) finish(i, pv[u], pa[u]);
     }
+    for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK)
+        finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f));
+    const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
+    if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------- spatial hash build
@@ -385,7 +486,8 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     } else if (e->ntiles) {
 #define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
-        e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->d_consts, e->prm, e->d_broken, e->d_pidx, e->grid)
+        e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->d_consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
+        e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
 #define SB_LAUNCH_TA(M, T) do { if (write_aux) SB_LAUNCH_T(M, T, true); else SB_LAUNCH_T(M, T, false); } while (0)
 #define SB_LAUNCH_TM(M) do { if (e->mat_mode == 2) SB_LAUNCH_TA(M, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(M, 1); else SB_LAUNCH_TA(M, 0); } while (0)
         if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(SB_COLLIDE_GRID);
@@ -420,4 +522,6 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
     if (!n) return;
     k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->n_ghost_p,
                                                                 e->d_ghost_b, e->n_ghost_b_copies, src);
+    // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
+    if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);
 }

@@ -13,7 +13,7 @@ import numpy as np
 from .layout import BEAM_STRIDE, LAYOUT_V1, METADATA_BYTES, PARTICLE_STRIDE, Buffers
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsoftbody_hip.so")
+LIB_PATH = os.environ.get("SOFTBODY_HIP_LIB") or os.path.join(_HERE, "csrc", "libsoftbody_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "softbody.h")
 
 COLLIDE_OFF, COLLIDE_ALLPAIRS, COLLIDE_GRID = 0, 1, 2
