@@ -85,9 +85,10 @@ def committed_traffic(workload, kernel):
             s = json.load(open(f))
             if s.get("bench", {}).get("config", {}).get("workload") != workload:
                 continue
-            for name, t in s.get("traffic", {}).items():
-                if name.startswith(kernel):
-                    best = (t["hbm_bytes_per_launch"], os.path.basename(f))
+            cand = [(max(v["launches"] for v in t.values() if isinstance(v, dict)), t["hbm_bytes_per_launch"])
+                    for name, t in s.get("traffic", {}).items() if name.startswith(kernel)]
+            if cand:  # the variant launched most often (the lean substep; the last one of a call also stores strain/stress)
+                best = (max(cand)[1], os.path.basename(f))
         except Exception:
             continue
     return best

@@ -17,8 +17,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)  # gpurun merges runs: newest wins
+    return g[-1] if g else None
 
 
 def counters(path):
