@@ -244,6 +244,9 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
                     b.strain[c] = res.strain;
                     b.stress[c] = res.stress;
                 }
+#if SB_ABLATE & 32 // diagnostic build: no LDS force accumulation
+                if (res.ax == 0x12345678) s_f[2 * la] = res.ay + res.bx + res.by;
+#else
                 if (la < n_own) {
                     atomicAdd(&s_f[2 * la], res.ax);
                     atomicAdd(&s_f[2 * la + 1], res.ay);
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
                     atomicAdd(&s_f[2 * lb], res.bx);
                     atomicAdd(&s_f[2 * lb + 1], res.by);
                 }
+#endif
                 if (res.broken) atomicOr(&broken[c >> 5], 1u << (c & 31));
             }
         }

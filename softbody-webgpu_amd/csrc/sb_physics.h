@@ -36,8 +36,19 @@ SB_DEV float sb_abs(float x) { return __uint_as_float(__float_as_uint(x) & 0x7ff
 // v_sqrt_f32; `__builtin_sqrtf` / operator `/` under -fhip-fp32-correctly-rounded-divide-sqrt
 // lower to the IEEE sequences (v_sqrt + residual fix-up; v_div_scale/fmas/fixup).  Checked in
 // the .s and by the bit-exact parity tests.
+#ifndef SB_ABLATE
+#define SB_ABLATE 0
+#endif
+#if SB_ABLATE & 16 // diagnostic build: raw 1-ulp v_sqrt_f32
+SB_DEV float sb_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
 SB_DEV float sb_sqrt(float x) { return __builtin_sqrtf(x); }
+#endif
+#if SB_ABLATE & 8 // diagnostic build: divide = multiply by the raw v_rcp_f32
+SB_DEV float sb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
 SB_DEV float sb_div(float a, float b) { return a / b; }
+#endif
 SB_DEV float sb_length(float x, float y) { return sb_sqrt(x * x + y * y); }
 
 // i32(f): truncate toward zero, saturating, NaN -> 0 (compute.wgsl:127-130).  That is exactly what
