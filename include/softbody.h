@@ -78,7 +78,10 @@ typedef struct sb_options {
     uint32_t path;           /* SB_PATH_* */
     uint32_t tile_particles; /* SB_PATH_TILED: target particles per tile (0 = default) */
     int32_t device_ordinal;  /* HIP device */
-    uint32_t reserved[5];
+    float grid_skin;         /* SB_COLLIDE_GRID: cells are 2r + 2*skin wide and the hash is rebuilt only when
+                              * some particle may have moved more than `skin` since the last build;
+                              * 0 = default (0.4 r), negative = rebuild every substep */
+    uint32_t reserved[4];
 } sb_options;
 
 /* Fill with the reference defaults: bounds 1000, radius 10, subticks 64, 65536/65536, v1,

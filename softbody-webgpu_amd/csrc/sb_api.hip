@@ -420,6 +420,7 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
     // leave it are clamped into edge cells (still a superset of the contacts, sb_physics.h)
     e->grid = SbGrid{};
     e->ncell = 0;
+    e->d_grid_ctl = nullptr;
     if (e->opt.collision_mode == SB_COLLIDE_GRID) {
         float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
         for (uint32_t s = 0; s < P; s++) {
@@ -428,7 +429,9 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
             miny = std::min(miny, py[s]); maxy = std::max(maxy, py[s]);
         }
         if (!(minx <= maxx)) minx = maxx = miny = maxy = 0.f;
-        float cell = e->prm.particle_radius * 2.0f * 1.015625f;
+        // skin: how far a particle may drift before the hash is rebuilt (SbGridCtl, sb_physics.h)
+        const float skin = e->opt.grid_skin < 0.f ? 0.f : (e->opt.grid_skin > 0.f ? e->opt.grid_skin : 0.4f * e->prm.particle_radius);
+        float cell = e->prm.particle_radius * 2.0f * 1.015625f + 2.0f * skin;
         const float S = e->prm.bounds_size;
         float mx = std::max(0.25f * (maxx - minx), 16.f * cell), my = std::max(0.25f * (maxy - miny), 16.f * cell);
         float x0 = std::max(0.f, minx - mx), x1 = std::min(S, maxx + mx);
@@ -452,9 +455,16 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         SB_TRY(dev_alloc(e, &boff, ((size_t)e->ncell + 1 + SB_SCAN_BLOCK - 1) / SB_SCAN_BLOCK));
         SB_TRY(dev_alloc(e, &e->d_rank, P));
         SB_TRY(dev_alloc(e, &e->d_rec, P));
+        SB_TRY(dev_alloc(e, &e->d_cell_of, P));
+        SB_TRY(dev_alloc(e, &e->d_grid_ctl, 1));
+        SbGridCtl ctl{};
+        ctl.force = 1;
+        ctl.skin = skin;
+        SB_HIP(e, hipMemcpy(e->d_grid_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
         e->grid.cell_scan = scan;
         e->grid.block_off = boff;
         e->grid.rec = e->d_rec;
+        e->grid.cell_of = e->d_cell_of;
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     SB_TRY(dev_alloc(e, &e->d_forces, P));
@@ -464,8 +474,7 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
     SB_TRY(dev_alloc(e, &e->d_dead_gen, B));
     SB_HIP(e, hipMemset(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4));
     e->delete_gen = 0;
-    SB_TRY(dev_alloc(e, &e->d_consts, 1));
-    SB_HIP(e, hipMemcpy(e->d_consts, md + 48, sizeof(SbConsts), hipMemcpyHostToDevice));
+    memcpy(&e->consts, md + 48, sizeof(SbConsts));
     SB_HIP(e, hipDeviceSynchronize());
     e->h_beams.swap(hb);
     e->loaded = true;
@@ -478,10 +487,7 @@ sb_status sb_write_user_input(sb_engine *e, const void *bytes32)
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_write_user_input before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     memcpy(e->h_metadata.data() + SB_USER_INPUT_OFFSET, bytes32, SB_USER_INPUT_BYTES);
-    // pageable source: the copy is staged before the call returns, so no pointer is retained
-    SB_HIP(e, hipMemcpyAsync((uint8_t *)e->d_consts + 32, e->h_metadata.data() + SB_USER_INPUT_OFFSET,
-                             SB_USER_INPUT_BYTES, hipMemcpyHostToDevice, e->stream));
-    SB_HIP(e, hipStreamSynchronize(e->stream));
+    memcpy((uint8_t *)&e->consts + 32, bytes32, SB_USER_INPUT_BYTES); // rides in the kernarg of later launches
     return SB_OK;
 }
 
@@ -491,8 +497,7 @@ sb_status sb_set_physics_constants(sb_engine *e, const float c8[8])
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_set_physics_constants before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     memcpy(e->h_metadata.data() + 48, c8, 32);
-    SB_HIP(e, hipMemcpyAsync(e->d_consts, e->h_metadata.data() + 48, 32, hipMemcpyHostToDevice, e->stream));
-    SB_HIP(e, hipStreamSynchronize(e->stream));
+    memcpy(&e->consts, c8, 32);
     return SB_OK;
 }
 
@@ -689,6 +694,15 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "kernels_per_substep")
         *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 5 : 0);
     else if (k == "grid_cells") *value = e->ncell;
+    else if (k == "grid_builds") {
+        *value = 0;
+        if (e->d_grid_ctl) {
+            SbGridCtl ctl;
+            SB_HIP(e, hipStreamSynchronize(e->stream));
+            SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+            *value = ctl.builds;
+        }
+    }
     else if (k == "material_mode") *value = e->mat_mode;
     else if (k == "materials") *value = e->nmat;
     else if (k == "local_index_bits") *value = e->lbits;

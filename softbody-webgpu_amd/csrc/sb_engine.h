@@ -52,7 +52,8 @@ struct sb_engine {
     // device state
     SbParticleArrays part[2]{};
     SbBeamArrays beams{};
-    SbConsts *d_consts = nullptr;
+    SbConsts consts{};             // metadata bytes 48..111, passed to every launch BY VALUE (kernarg):
+                                   // scalar-cache lines are not reliably refreshed between launches on this stack
     uint32_t *d_pidx = nullptr;    // data index per internal particle (collision tie-break :153)
     uint32_t *d_pslot = nullptr;
     int2 *d_forces = nullptr;      // atomic path accumulator (compute.wgsl:68-69)
@@ -89,7 +90,9 @@ struct sb_engine {
     uint32_t *d_cell_scan = nullptr; // counts, then in-block exclusive scan
     uint32_t *d_block_off = nullptr; // per 2048-cell block
     uint32_t *d_rank = nullptr;      // per particle: arrival rank inside its cell
-    float4 *d_rec = nullptr;         // particles sorted by cell
+    uint32_t *d_cell_of = nullptr;   // per particle: cell at the last rebuild
+    uint2 *d_rec = nullptr;          // {slot, index} sorted by cell
+    SbGridCtl *d_grid_ctl = nullptr; // rebuild decision state (device resident: no host sync per substep)
 
     size_t device_bytes = 0;
     std::vector<void *> allocs;

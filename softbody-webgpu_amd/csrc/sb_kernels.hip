@@ -7,6 +7,8 @@
 //   SB_PATH_TILED   k_substep_tiled: one workgroup per particle tile; beam forces are summed
 //                   with LDS integer atomics and consumed in the same launch.
 // Both are HBM-bandwidth-bound (no MFMA: < 1 flop/byte).
+#include <algorithm>
+
 #include "sb_engine.h"
 
 #define SB_BLOCK 256
@@ -44,11 +46,11 @@ __global__ __launch_bounds__(SB_BLOCK) void k_beams_atomic(SbBeamArrays b, uint3
 template <int MODE>
 __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbParticleArrays w,
                                                         int2 *forces, uint32_t P,
-                                                        const SbConsts *__restrict__ cp, SbParams prm,
-                                                        const uint32_t *__restrict__ pidx, SbGrid grid)
+                                                        const SbConsts c, SbParams prm,
+                                                        const uint32_t *__restrict__ pidx, SbGrid grid,
+                                                        SbGridCtl *ctl)
 {
     __shared__ float2 s_pos[SB_BLOCK];
-    const SbConsts c = *cp;
     uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
     bool active = i < P;
     SbParticle particle, self;
@@ -82,11 +84,16 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         }
     }
     if (MODE == SB_COLLIDE_GRID && active)
-        sb_collide_grid(grid, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.vel);
+        sb_collide_grid(grid, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
+    float moved = 0.0f;
+    if (active) {
+        int2 f = forces[i];
+        forces[i] = make_int2(0, 0); // atomicExchange(..., 0), :184-185
+        sb_particle_finish(prm, c, particle, f.x, f.y);
+        moved = fmaxf(sb_abs(particle.p.x - self.p.x), sb_abs(particle.p.y - self.p.y)) * 1.4142137f;
+    }
+    if (MODE == SB_COLLIDE_GRID) sb_track_displacement(ctl, moved);
     if (!active) return;
-    int2 f = forces[i];
-    forces[i] = make_int2(0, 0); // atomicExchange(..., 0), :184-185
-    sb_particle_finish(prm, c, particle, f.x, f.y);
     w.pos[i] = particle.p;
     w.vel[i] = particle.v;
     w.acc[i] = particle.a;
@@ -119,9 +126,9 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
     const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits,
-    const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts *__restrict__ cp, SbParams prm,
-    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid, const uint32_t *__restrict__ acc_flag_r,
-    uint32_t *acc_flag_w)
+    const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts c, SbParams prm,
+    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid, SbGridCtl *ctl,
+    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
@@ -141,7 +148,9 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     // acc_flag[buffer][tile] == 0 guarantees that every acceleration of the tile in that buffer IS
     // zero (true for almost every tile: compute.wgsl:188 zeroes a, only border friction :192,:196
     // sets it), so the 8 B/particle read and the 8 B/particle write of zeros can both be skipped.
-    const bool acc_r = acc_flag_r[tile] != 0u, acc_w_dirty = acc_flag_w[tile] != 0u;
+    // (flags are rewritten by every launch: read them at agent scope, not through the scalar cache)
+    const bool acc_r = __hip_atomic_load(&acc_flag_r[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    const bool acc_w_dirty = __hip_atomic_load(&acc_flag_w[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     uint32_t hidx = 0;
     const bool has_halo = tid < n_halo;
     if (has_halo) hidx = halo_idx[h0 + tid];
@@ -270,17 +279,18 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     __syncthreads();
 
     // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
-    const SbConsts c = *cp;
     bool any_acc = false;
+    float moved = 0.0f;
     auto finish = [&](uint32_t i, float2 vel, float2 acc) {
         const uint32_t g = p0 + i;
         SbParticle particle;
         particle.p = s_pos[i];
         particle.v = vel;
         particle.a = acc;
+        const float2 p_old = particle.p;
         if (MODE == SB_COLLIDE_GRID) {
             const SbParticle self = particle; // :141
-            sb_collide_grid(grid, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx, r.vel);
+            sb_collide_grid(grid, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx, r.pos, r.vel);
         }
 #if SB_ABLATE & 2 // diagnostic build: particle arithmetic replaced by a data-dependent dummy
         particle.v.x += (float)s_f[2 * i] * prm.time_step;
@@ -288,6 +298,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
 #else
         sb_particle_finish(prm, c, particle, s_f[2 * i], s_f[2 * i + 1]);
 #endif
+        if (MODE == SB_COLLIDE_GRID)
+            moved = fmaxf(moved, fmaxf(sb_abs(particle.p.x - p_old.x), sb_abs(particle.p.y - p_old.y)) * 1.4142137f);
         w.pos[g] = particle.p;
         w.vel[g] = particle.v;
         const bool nz = (__float_as_uint(particle.a.x) | __float_as_uint(particle.a.y)) != 0u; // -0.0 counts
@@ -301,27 +313,56 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     }
     for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK)
         finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f));
+    if (MODE == SB_COLLIDE_GRID) sb_track_displacement(ctl, moved);
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
     if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------- spatial hash build
 
-// counts per cell, and each particle's arrival rank inside its cell (one returning atomic per
-// particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_count(const float2 *__restrict__ pos, uint32_t P, SbGrid g,
-                                                         uint32_t *cell_count, uint32_t *rank)
+// One thread decides whether this substep rebuilds the hash (SbGridCtl in sb_physics.h).  Every
+// build kernel below returns at once when it does not, so a skipped build costs a few empty launches.
+__global__ void k_grid_decide(SbGridCtl *ctl)
 {
+    // step_max / force are written by atomics and memsets of earlier launches: read them with
+    // agent-scope loads (L2), never through the scalar cache
+    const uint32_t step_bits = __hip_atomic_load(&ctl->step_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t force = __hip_atomic_load(&ctl->force, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float accum = ctl->accum + __uint_as_float(step_bits); // displacement bound up to the READ state
+    ctl->step_max = 0u;
+    const bool rebuild = force != 0u || !(accum <= ctl->skin); // NaN-safe: rebuild unless provably fine
+    ctl->force = 0u;
+    ctl->rebuild = rebuild ? 1u : 0u;
+    ctl->accum = rebuild ? 0.0f : accum;
+    ctl->builds += rebuild ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_zero(uint32_t *cell, uint32_t n, const SbGridCtl *__restrict__ ctl)
+{
+    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    for (uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x; i < n; i += gridDim.x * SB_BLOCK) cell[i] = 0u;
+}
+
+// counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
+// per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_count(const float2 *__restrict__ pos, uint32_t P, SbGrid g,
+                                                         uint32_t *cell_count, uint32_t *cell_of, uint32_t *rank,
+                                                         const SbGridCtl *__restrict__ ctl)
+{
+    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (i >= P) return;
     float2 p = pos[i];
     uint32_t c = sb_grid_coord(p.y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p.x, g.x0, g.cell, g.nx);
+    cell_of[i] = c;
     rank[i] = atomicAdd(&cell_count[c], 1u);
 }
 
 // in-place exclusive scan of each 2048-cell block (256 threads x 8 cells) + the block totals
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell, uint32_t n, uint32_t *block_sum)
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell, uint32_t n, uint32_t *block_sum,
+                                                               const SbGridCtl *__restrict__ ctl)
 {
+    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     __shared__ uint32_t s_wave[SB_BLOCK / 64];
     const uint32_t tid = threadIdx.x, base = blockIdx.x * SB_SCAN_BLOCK + tid * 8u;
     uint32_t v[8], sum = 0;
@@ -350,8 +391,10 @@ __global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell, u
 }
 
 // exclusive scan of the block totals, one workgroup walking 256 at a time with a carry
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum, uint32_t nblocks)
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum, uint32_t nblocks,
+                                                             const SbGridCtl *__restrict__ ctl)
 {
+    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     __shared__ uint32_t s_wave[SB_BLOCK / 64];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x;
@@ -376,17 +419,16 @@ __global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum
     }
 }
 
-// particles -> records sorted by cell
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scatter(const float2 *__restrict__ pos,
-                                                           const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
-                                                           const uint32_t *__restrict__ rank, float4 *rec)
+// particles -> {slot, index} records sorted by cell
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scatter(const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
+                                                           const uint32_t *__restrict__ rank, uint2 *rec,
+                                                           const SbGridCtl *__restrict__ ctl)
 {
+    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (i >= P) return;
-    float2 p = pos[i];
-    uint32_t c = sb_grid_coord(p.y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p.x, g.x0, g.cell, g.nx);
-    uint32_t k = sb_grid_start(g, c) + rank[i];
-    rec[k] = make_float4(p.x, p.y, __uint_as_float(pslot[i]), __uint_as_float(i));
+    uint32_t k = sb_grid_start(g, g.cell_of[i]) + rank[i];
+    rec[k] = make_uint2(pslot[i], i);
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -464,16 +506,18 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
     const uint32_t mode = e->opt.collision_mode;
     if (mode == SB_COLLIDE_GRID && e->P) {
-        // rebuild the spatial hash from the READ state
+        // (re)build the spatial hash from the READ state when the displacement bound demands it
         uint32_t *counts = const_cast<uint32_t *>(e->grid.cell_scan);
         uint32_t *boff = const_cast<uint32_t *>(e->grid.block_off);
         const uint32_t n = e->ncell + 1, nblocks = cdiv(n, SB_SCAN_BLOCK);
-        (void)hipMemsetAsync(counts, 0, (size_t)n * 4, e->stream);
-        k_grid_count<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(r.pos, e->P, e->grid, counts, e->d_rank);
-        k_grid_scan_blocks<<<nblocks, SB_BLOCK, 0, e->stream>>>(counts, n, boff);
-        k_grid_scan_sums<<<1, SB_BLOCK, 0, e->stream>>>(boff, nblocks);
-        k_grid_scatter<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(r.pos, e->d_pslot, e->P, e->grid, e->d_rank,
-                                                                       e->d_rec);
+        k_grid_decide<<<1, 1, 0, e->stream>>>(e->d_grid_ctl);
+        k_grid_zero<<<std::min(cdiv(n, SB_BLOCK), 2048u), SB_BLOCK, 0, e->stream>>>(counts, n, e->d_grid_ctl);
+        k_grid_count<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(r.pos, e->P, e->grid, counts, e->d_cell_of,
+                                                                     e->d_rank, e->d_grid_ctl);
+        k_grid_scan_blocks<<<nblocks, SB_BLOCK, 0, e->stream>>>(counts, n, boff, e->d_grid_ctl);
+        k_grid_scan_sums<<<1, SB_BLOCK, 0, e->stream>>>(boff, nblocks, e->d_grid_ctl);
+        k_grid_scatter<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->d_pslot, e->P, e->grid, e->d_rank, e->d_rec,
+                                                                       e->d_grid_ctl);
     }
     if (e->path == SB_PATH_ATOMIC) {
         if (e->nbeam)
@@ -481,7 +525,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
                                                                                e->d_forces, e->d_broken);
         if (e->P) {
             dim3 g(cdiv(e->P, SB_BLOCK));
-#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->d_consts, e->prm, e->d_pidx, e->grid)
+#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, e->d_grid_ctl)
             if (mode == SB_COLLIDE_ALLPAIRS) SB_LAUNCH_P(SB_COLLIDE_ALLPAIRS);
             else if (mode == SB_COLLIDE_GRID) SB_LAUNCH_P(SB_COLLIDE_GRID);
             else SB_LAUNCH_P(SB_COLLIDE_OFF);
@@ -490,8 +534,8 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     } else if (e->ntiles) {
 #define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
-        e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->d_consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
-        e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+        e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
+        e->d_grid_ctl, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
 #define SB_LAUNCH_TA(M, T) do { if (write_aux) SB_LAUNCH_T(M, T, true); else SB_LAUNCH_T(M, T, false); } while (0)
 #define SB_LAUNCH_TM(M) do { if (e->mat_mode == 2) SB_LAUNCH_TA(M, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(M, 1); else SB_LAUNCH_TA(M, 0); } while (0)
         if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(SB_COLLIDE_GRID);
@@ -526,6 +570,7 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
     if (!n) return;
     k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->n_ghost_p,
                                                                 e->d_ghost_b, e->n_ghost_b_copies, src);
+    if (e->d_grid_ctl) (void)hipMemsetAsync(&e->d_grid_ctl->force, 0x01, 4, e->stream); // ghosts jumped: rebin
     // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
     if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);
 }

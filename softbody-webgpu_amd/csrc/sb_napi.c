@@ -161,6 +161,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
             if (opt_number(env, argv[0], "path", &d)) o.path = (uint32_t)d;
             if (opt_number(env, argv[0], "tileParticles", &d)) o.tile_particles = (uint32_t)d;
             if (opt_number(env, argv[0], "device", &d)) o.device_ordinal = (int32_t)d;
+            if (opt_number(env, argv[0], "gridSkin", &d)) o.grid_skin = (float)d;
         }
     }
     sb_engine *e = NULL;

@@ -232,11 +232,35 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
 struct SbGrid {
     const uint32_t *cell_scan; // per cell: exclusive scan inside its 2048-cell block
     const uint32_t *block_off; // per 2048-cell block: offset of the block
-    const float4 *rec;         // sorted by cell: {p.x, p.y, bits(slot), bits(internal index)}
+    const uint2 *rec;          // sorted by cell: {slot, internal index}
+    const uint32_t *cell_of;   // per particle: its cell at the last rebuild
     float x0, y0, cell;
     uint32_t nx, ny;
 };
+// The hash is rebuilt only when needed: cells are 2r*(1+1/64) + 2*skin wide, and a rebuild happens as
+// soon as the sum of per-substep maximum displacements since the last build exceeds skin.  Until then
+// every particle is within skin of where it was binned, so two particles closer than 2r NOW were closer
+// than 2r + 2*skin THEN and sit in the same or adjacent cells of the (stale) binning: still a superset.
+// Candidates are therefore looked up in the cells of the last build but tested at their CURRENT positions.
+struct SbGridCtl {
+    uint32_t rebuild;     // 1 while the build kernels of this substep must run
+    uint32_t force;       // set by the host (upload, halo unpack): rebuild unconditionally
+    uint32_t step_max;    // float bits: max displacement of any particle in the substep just run
+    float accum;          // sum of step maxima since the last build
+    float skin;
+    uint32_t builds;      // statistics
+};
 #define SB_SCAN_BLOCK 2048u
+
+// largest displacement of any particle in this substep -> ctl->step_max (positive float bits order
+// like unsigned integers; anything not provably small, NaN included, reads as "huge")
+SB_DEV void sb_track_displacement(SbGridCtl *ctl, float m)
+{
+    m = (m < 1.0e30f) ? m : 1.0e30f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63u) == 0u && m > 0.0f) atomicMax(&ctl->step_max, __float_as_uint(m));
+}
 
 SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
 {
@@ -253,11 +277,13 @@ SB_DEV uint32_t sb_grid_start(const SbGrid &g, uint32_t c) { return g.cell_scan[
 // reference loop, so skipping them changes nothing; the result is bit-identical to all-pairs.
 SB_DEV void sb_collide_grid(const SbGrid &g, const SbParams &prm, float friction, float elasticity_coeff,
                             SbParticle &particle, const SbParticle &self, uint32_t i,
-                            const uint32_t *__restrict__ pidx, const float2 *__restrict__ vel_r)
+                            const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
+                            const float2 *__restrict__ vel_r)
 {
     const float two_r = prm.particle_radius * 2.0f;
-    const uint32_t cx = sb_grid_coord(self.p.x, g.x0, g.cell, g.nx);
-    const uint32_t cy = sb_grid_coord(self.p.y, g.y0, g.cell, g.ny);
+    const float far2 = two_r * two_r * 1.001f;
+    const uint32_t cell = g.cell_of[i]; // where this particle was binned at the last rebuild
+    const uint32_t cx = cell % g.nx, cy = cell / g.nx;
     const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < g.nx ? cx + 1u : g.nx - 1u;
     uint32_t rb[3], re[3];
 #pragma unroll
@@ -278,14 +304,20 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbParams &prm, float friction
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             for (uint32_t k = rb[r]; k < re[r]; k++) {
-                const float4 rec = g.rec[k];
-                const uint32_t slot = __float_as_uint(rec.z), id = __float_as_uint(rec.w);
+                const uint2 rec = g.rec[k];
+                const uint32_t slot = rec.x, id = rec.y;
                 if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
-                const float d = sb_length(rec.x - self.p.x, rec.y - self.p.y);
+                const float2 q = pos_r[id];
+                const float ex = q.x - self.p.x, ey = q.y - self.p.y;
+                const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
+                // sqrt is monotone: d2 clearly above (2r)^2 cannot give d < 2r (and is not 0), so the
+                // correctly rounded root is only evaluated for the few candidates near contact range
+                if (d2 > far2) continue;
+                const float d = sb_sqrt(d2);
                 if (d == 0.0f || d < two_r) {
                     best_slot = slot;
                     best_id = id;
-                    best_p = make_float2(rec.x, rec.y);
+                    best_p = q;
                 }
             }
         }

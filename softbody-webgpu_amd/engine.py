@@ -35,7 +35,8 @@ class SbOptions(ctypes.Structure):
                 ("max_particles", ctypes.c_uint32), ("max_beams", ctypes.c_uint32),
                 ("layout", ctypes.c_uint32), ("collision_mode", ctypes.c_uint32),
                 ("path", ctypes.c_uint32), ("tile_particles", ctypes.c_uint32),
-                ("device_ordinal", ctypes.c_int32), ("reserved", ctypes.c_uint32 * 5)]
+                ("device_ordinal", ctypes.c_int32), ("grid_skin", ctypes.c_float),
+                ("reserved", ctypes.c_uint32 * 4)]
 
 
 _lib = None
@@ -112,13 +113,14 @@ class Engine:
 
     def __init__(self, bounds_size=1000.0, particle_radius=10.0, subticks=64, layout=LAYOUT_V1,
                  max_particles=65536, max_beams=65536, collision_mode=COLLIDE_ALLPAIRS,
-                 path=PATH_AUTO, tile_particles=0, device=0):
+                 path=PATH_AUTO, tile_particles=0, device=0, grid_skin=0.0):
         L = load_library()
         o = SbOptions()
         L.sb_default_options(ctypes.byref(o))
         o.bounds_size, o.particle_radius, o.subticks = bounds_size, particle_radius, subticks
         o.max_particles, o.max_beams, o.layout = max_particles, max_beams, layout
         o.collision_mode, o.path, o.tile_particles, o.device_ordinal = collision_mode, path, tile_particles, device
+        o.grid_skin = grid_skin
         self._h = ctypes.c_void_p()
         st = L.sb_create(ctypes.byref(o), ctypes.byref(self._h))
         if st != 0:

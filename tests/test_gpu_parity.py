@@ -291,3 +291,28 @@ def test_force_saturation_and_nonfinite(sb, oracle):
         assert_same(got, exp, "saturation path %d" % path)
         v = exp.particles[:4, 2:4]
         assert np.abs(v).max() == np.float32(32768.0 / 64.0)  # (2^31 / 65536) * dt: the saturated force
+
+
+def test_user_input_changes_between_frames(sb, oracle):
+    """The reference uploads user input every frame (engineWorker.ts:636-642) and constants at any time:
+    values changed AFTER kernels have already run must reach the next launch (they travel in the kernarg;
+    a device-resident copy read through the scalar cache went stale between launches on this stack)."""
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    eng = sb.Engine(layout=1, max_particles=256, max_beams=512, collision_mode=ALLPAIRS)
+    ref = oracle.OracleEngine(1000.0, 10.0, 64, 1, ALLPAIRS)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    b = buf.copy()
+    for k in range(4):
+        b.set_user_input(applied_force=(0.2 * k, -0.1 * k), mouse_pos=(200.0 + 30 * k, 150.0), mouse_vel=(1.0 * k, 2.0),
+                         mouse_active=bool(k % 2))
+        eng.write_user_input(b.user_input_bytes())
+        ref.write_user_input(b.user_input_bytes())
+        c = np.array([0.05 * k, -0.5 - 0.1 * k, 0.5, 0.2, 0.5, 0.1, 0.001 * (k + 1), 2.0], "f4")
+        eng.set_physics_constants(c)
+        ref.set_physics_constants(c)
+        eng.frame()
+        ref.frame()
+        got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+        assert_same(got, exp, "frame %d" % k)
+    eng.destroy()
