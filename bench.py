@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ghost-depth", type=int, default=16,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
+    ap.add_argument("--grid-skin", type=float, default=0.0, help="spatial-hash skin (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -134,7 +135,7 @@ def main():
     B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=64, layout=2,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
-                    path=path, tile_particles=a.tile, device=local)
+                    path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin)
     eng.write_buffers(buf)
     if plan is None:
         stepper = eng.step
@@ -198,7 +199,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "particles_total": P_total, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
-                       "tiles": eng.info("tiles"),
+                       "tiles": eng.info("tiles"), "grid_builds": eng.info("grid_builds") if mode == 2 else None,
                        "parallelism": "single GPU" if world == 1 else
                        "%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, RCCL neighbour "
                        "send/recv of ghost p,v,a + beam target/last every %d substeps" % (world, W, a.ghost_depth, a.ghost_depth)},

@@ -450,21 +450,27 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         e->grid.nx = std::max(1u, (uint32_t)std::ceil((double)(x1 - x0) / cell));
         e->grid.ny = std::max(1u, (uint32_t)std::ceil((double)(y1 - y0) / cell));
         e->ncell = e->grid.nx * e->grid.ny;
-        uint32_t *scan = nullptr, *boff = nullptr;
-        SB_TRY(dev_alloc(e, &scan, (size_t)e->ncell + 1));
-        SB_TRY(dev_alloc(e, &boff, ((size_t)e->ncell + 1 + SB_SCAN_BLOCK - 1) / SB_SCAN_BLOCK));
+        const size_t n1 = (size_t)e->ncell + 1;
+        SB_TRY(dev_alloc(e, &e->d_cell_cnt, n1));
+        SB_HIP(e, hipMemset(e->d_cell_cnt, 0, n1 * 4));
+        SB_TRY(dev_alloc(e, &e->d_cell_scan, n1));
+        SB_TRY(dev_alloc(e, &e->d_cell_start, n1));
+        SB_TRY(dev_alloc(e, &e->d_block_off, (n1 + SB_SCAN_BLOCK - 1) / SB_SCAN_BLOCK));
         SB_TRY(dev_alloc(e, &e->d_rank, P));
         SB_TRY(dev_alloc(e, &e->d_rec, P));
         SB_TRY(dev_alloc(e, &e->d_cell_of, P));
         SB_TRY(dev_alloc(e, &e->d_grid_ctl, 1));
+        const size_t nblk = std::max<size_t>(e->ntiles, (P + 255) / 256) + 1;
+        SB_TRY(dev_alloc(e, &e->d_blk_max, nblk));
+        SB_HIP(e, hipMemset(e->d_blk_max, 0, nblk * 4));
         SbGridCtl ctl{};
         ctl.force = 1;
         ctl.skin = skin;
         SB_HIP(e, hipMemcpy(e->d_grid_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
-        e->grid.cell_scan = scan;
-        e->grid.block_off = boff;
+        e->grid.cell_start = e->d_cell_start;
         e->grid.rec = e->d_rec;
         e->grid.cell_of = e->d_cell_of;
+        e->grid.skin = skin;
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     SB_TRY(dev_alloc(e, &e->d_forces, P));

@@ -84,15 +84,18 @@ struct sb_engine {
     uint32_t nmat = 0;
     float *d_mat = nullptr;   // [nmat][5] = length, spring, damp, yield_strain, strain_break_limit
 
-    // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state every substep
+    // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state when the displacement bound demands it
     SbGrid grid{};
-    uint32_t ncell = 0;              // nx*ny (+1 spare entry in the arrays)
-    uint32_t *d_cell_scan = nullptr; // counts, then in-block exclusive scan
-    uint32_t *d_block_off = nullptr; // per 2048-cell block
-    uint32_t *d_rank = nullptr;      // per particle: arrival rank inside its cell
-    uint32_t *d_cell_of = nullptr;   // per particle: cell at the last rebuild
-    uint2 *d_rec = nullptr;          // {slot, index} sorted by cell
-    SbGridCtl *d_grid_ctl = nullptr; // rebuild decision state (device resident: no host sync per substep)
+    uint32_t ncell = 0;               // nx*ny (+1 spare entry in the per-cell arrays)
+    uint32_t *d_cell_cnt = nullptr;   // per cell: arrival counter (zero between builds)
+    uint32_t *d_cell_scan = nullptr;  // per cell: exclusive scan inside its 2048-cell block
+    uint32_t *d_block_off = nullptr;  // per 2048-cell block
+    uint32_t *d_cell_start = nullptr; // per cell: absolute first record
+    uint32_t *d_rank = nullptr;       // per particle: arrival rank inside its cell
+    uint32_t *d_cell_of = nullptr;    // per particle: cell at the last build
+    float4 *d_rec = nullptr;          // records sorted by cell
+    SbGridCtl *d_grid_ctl = nullptr;  // rebuild decision state (device resident: no host sync per substep)
+    uint32_t *d_blk_max = nullptr;    // per workgroup of the particle kernel: largest displacement (float bits)
 
     size_t device_bytes = 0;
     std::vector<void *> allocs;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
                                                         int2 *forces, uint32_t P,
                                                         const SbConsts c, SbParams prm,
                                                         const uint32_t *__restrict__ pidx, SbGrid grid,
-                                                        SbGridCtl *ctl)
+                                                        uint32_t *blk_max)
 {
     __shared__ float2 s_pos[SB_BLOCK];
     uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
@@ -83,8 +83,10 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
             }
         }
     }
-    if (MODE == SB_COLLIDE_GRID && active)
-        sb_collide_grid(grid, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
+    if (MODE == SB_COLLIDE_GRID && active) {
+        const SbGridRanges rg = sb_grid_ranges(grid, grid.cell_of[i]);
+        sb_collide_grid(grid, rg, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
+    }
     float moved = 0.0f;
     if (active) {
         int2 f = forces[i];
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         sb_particle_finish(prm, c, particle, f.x, f.y);
         moved = fmaxf(sb_abs(particle.p.x - self.p.x), sb_abs(particle.p.y - self.p.y)) * 1.4142137f;
     }
-    if (MODE == SB_COLLIDE_GRID) sb_track_displacement(ctl, moved);
+    if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
     if (!active) return;
     w.pos[i] = particle.p;
     w.vel[i] = particle.v;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
     const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits,
     const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts c, SbParams prm,
-    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid, SbGridCtl *ctl,
+    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid, uint32_t *blk_max,
     const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
@@ -184,6 +186,19 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     for (uint32_t i = tid + SB_BLOCK; i < n_halo; i += SB_BLOCK) s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
     if (MAT != 0)
         for (uint32_t i = tid; i < nmat * 5u; i += SB_BLOCK) s_mat[i] = mat_tab[i];
+    // SB_COLLIDE_GRID: the record ranges of each particle's three cell rows are fetched here, so the two
+    // dependent lookups (particle -> stale cell -> cell starts) are long done when phase 2 needs them
+    SbGridRanges rg[SB_UNROLL];
+    if (MODE == SB_COLLIDE_GRID) {
+        uint32_t qcell[SB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; u++) {
+            const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+            qcell[u] = grid.cell_of[p0 + (i < n_own ? i : 0u)];
+        }
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; u++) rg[u] = sb_grid_ranges(grid, qcell[u]);
+    }
     __syncthreads();
 
     // Beam phase.  The slice is walked in batches of SB_UNROLL x 256 copies: all global loads of a
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
     bool any_acc = false;
     float moved = 0.0f;
-    auto finish = [&](uint32_t i, float2 vel, float2 acc) {
+    auto finish = [&](uint32_t i, float2 vel, float2 acc, const SbGridRanges &ranges) {
         const uint32_t g = p0 + i;
         SbParticle particle;
         particle.p = s_pos[i];
@@ -290,7 +305,10 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         const float2 p_old = particle.p;
         if (MODE == SB_COLLIDE_GRID) {
             const SbParticle self = particle; // :141
-            sb_collide_grid(grid, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx, r.pos, r.vel);
+#if !(SB_ABLATE & 64) // diagnostic build: no collision scan
+            sb_collide_grid(grid, ranges, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx,
+                            r.pos, r.vel);
+#endif
         }
 #if SB_ABLATE & 2 // diagnostic build: particle arithmetic replaced by a data-dependent dummy
         particle.v.x += (float)s_f[2 * i] * prm.time_step;
@@ -309,66 +327,84 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
 #pragma unroll
     for (int u = 0; u < SB_UNROLL; u++) {
         const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
-        if (i < n_own) finish(i, pv[u], pa[u]);
+        if (i < n_own) finish(i, pv[u], pa[u], rg[u]);
     }
-    for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK)
-        finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f));
-    if (MODE == SB_COLLIDE_GRID) sb_track_displacement(ctl, moved);
+    for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK) {
+        SbGridRanges tail{};
+        if (MODE == SB_COLLIDE_GRID) tail = sb_grid_ranges(grid, grid.cell_of[p0 + i]);
+        finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f), tail);
+    }
+#if !(SB_ABLATE & 128) // diagnostic build: no displacement tracking
+    if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
+#endif
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
     if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------- spatial hash build
 
-// One thread decides whether this substep rebuilds the hash (SbGridCtl in sb_physics.h).  Every
-// build kernel below returns at once when it does not, so a skipped build costs a few empty launches.
-__global__ void k_grid_decide(SbGridCtl *ctl)
-{
-    // step_max / force are written by atomics and memsets of earlier launches: read them with
-    // agent-scope loads (L2), never through the scalar cache
-    const uint32_t step_bits = __hip_atomic_load(&ctl->step_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t force = __hip_atomic_load(&ctl->force, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float accum = ctl->accum + __uint_as_float(step_bits); // displacement bound up to the READ state
-    ctl->step_max = 0u;
-    const bool rebuild = force != 0u || !(accum <= ctl->skin); // NaN-safe: rebuild unless provably fine
-    ctl->force = 0u;
-    ctl->rebuild = rebuild ? 1u : 0u;
-    ctl->accum = rebuild ? 0.0f : accum;
-    ctl->builds += rebuild ? 1u : 0u;
-}
+// Four launches, each of which returns at once unless ctl->rebuild is set (by the last workgroup of
+// the previous substep's particle kernel, sb_track_displacement): count -> block scan -> scan of the
+// block sums -> scatter + absolute cell starts.  The count array is re-zeroed by the block scan, so no
+// separate clear is needed.
 
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_zero(uint32_t *cell, uint32_t n, const SbGridCtl *__restrict__ ctl)
+// One workgroup reduces the per-workgroup displacement maxima of the substep just run and decides
+// whether the coming substep rebuilds the hash (SbGridCtl, sb_physics.h).  Everything it reads was
+// written by earlier launches: agent-scope loads only.
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_decide(SbGridCtl *ctl, uint32_t *blk_max, uint32_t nblk)
 {
-    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    for (uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x; i < n; i += gridDim.x * SB_BLOCK) cell[i] = 0u;
+    __shared__ float s_wave_max[SB_BLOCK / 64];
+    float m = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nblk; i += SB_BLOCK) {
+        m = fmaxf(m, __uint_as_float(SB_AGENT_LOAD(&blk_max[i])));
+        SB_AGENT_STORE(&blk_max[i], 0u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63u) == 0u) s_wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float step = 0.0f;
+        for (int w = 0; w < SB_BLOCK / 64; w++) step = fmaxf(step, s_wave_max[w]);
+        const float accum = SB_AGENT_LOAD(&ctl->accum) + step; // bound for the READ state of this substep
+        const bool rebuild = SB_AGENT_LOAD(&ctl->force) != 0u || !(accum <= SB_AGENT_LOAD(&ctl->skin)); // NaN-safe
+        SB_AGENT_STORE(&ctl->force, 0u);
+        SB_AGENT_STORE(&ctl->rebuild, rebuild ? 1u : 0u);
+        SB_AGENT_STORE(&ctl->accum, rebuild ? 0.0f : accum);
+        if (rebuild) SB_AGENT_STORE(&ctl->builds, SB_AGENT_LOAD(&ctl->builds) + 1u);
+    }
 }
 
 // counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
 // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
 __global__ __launch_bounds__(SB_BLOCK) void k_grid_count(const float2 *__restrict__ pos, uint32_t P, SbGrid g,
-                                                         uint32_t *cell_count, uint32_t *cell_of, uint32_t *rank,
-                                                         const SbGridCtl *__restrict__ ctl)
+                                                         uint32_t *cell_cnt, uint32_t *cell_of, uint32_t *rank,
+                                                         const SbGridCtl *ctl)
 {
-    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
     uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (i >= P) return;
     float2 p = pos[i];
     uint32_t c = sb_grid_coord(p.y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p.x, g.x0, g.cell, g.nx);
     cell_of[i] = c;
-    rank[i] = atomicAdd(&cell_count[c], 1u);
+    rank[i] = atomicAdd(&cell_cnt[c], 1u);
 }
 
-// in-place exclusive scan of each 2048-cell block (256 threads x 8 cells) + the block totals
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell, uint32_t n, uint32_t *block_sum,
-                                                               const SbGridCtl *__restrict__ ctl)
+// exclusive scan of each 2048-cell block (256 threads x 8 cells) + the block totals; clears the counts
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell_cnt, uint32_t *cell_scan, uint32_t n,
+                                                               uint32_t *block_sum, const SbGridCtl *ctl)
 {
-    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
     __shared__ uint32_t s_wave[SB_BLOCK / 64];
     const uint32_t tid = threadIdx.x, base = blockIdx.x * SB_SCAN_BLOCK + tid * 8u;
     uint32_t v[8], sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        uint32_t x = base + k < n ? cell[base + k] : 0u;
+        uint32_t x = 0u;
+        if (base + k < n) {
+            x = cell_cnt[base + k];
+            cell_cnt[base + k] = 0u; // ready for the next build
+        }
         v[k] = sum;
         sum += x;
     }
@@ -386,15 +422,14 @@ __global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell, u
     const uint32_t excl = wave_off + inc - sum;
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        if (base + k < n) cell[base + k] = v[k] + excl;
+        if (base + k < n) cell_scan[base + k] = v[k] + excl;
     if (tid == SB_BLOCK - 1) block_sum[blockIdx.x] = excl + sum;
 }
 
 // exclusive scan of the block totals, one workgroup walking 256 at a time with a carry
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum, uint32_t nblocks,
-                                                             const SbGridCtl *__restrict__ ctl)
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum, uint32_t nblocks, const SbGridCtl *ctl)
 {
-    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
     __shared__ uint32_t s_wave[SB_BLOCK / 64];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x;
@@ -419,16 +454,24 @@ __global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum
     }
 }
 
-// particles -> {slot, index} records sorted by cell
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scatter(const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
-                                                           const uint32_t *__restrict__ rank, uint2 *rec,
-                                                           const SbGridCtl *__restrict__ ctl)
+// particles -> records sorted by cell, and the absolute first-record index of every cell
+__global__ __launch_bounds__(SB_BLOCK) void k_grid_scatter(const float2 *__restrict__ pos,
+                                                           const uint32_t *__restrict__ pslot, uint32_t P,
+                                                           const uint32_t *__restrict__ cell_of,
+                                                           const uint32_t *__restrict__ cell_scan,
+                                                           const uint32_t *__restrict__ block_off,
+                                                           const uint32_t *__restrict__ rank, float4 *rec,
+                                                           uint32_t *cell_start, uint32_t ncell1, const SbGridCtl *ctl)
 {
-    if (!__hip_atomic_load(&ctl->rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    uint32_t k = sb_grid_start(g, g.cell_of[i]) + rank[i];
-    rec[k] = make_uint2(pslot[i], i);
+    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
+    const uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (i < P) {
+        const uint32_t c = cell_of[i];
+        const float2 p = pos[i];
+        rec[cell_scan[c] + block_off[c / SB_SCAN_BLOCK] + rank[i]] =
+            make_float4(p.x, p.y, __uint_as_float(pslot[i]), __uint_as_float(i));
+    }
+    for (uint32_t c = i; c < ncell1; c += gridDim.x * SB_BLOCK) cell_start[c] = cell_scan[c] + block_off[c / SB_SCAN_BLOCK];
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -507,17 +550,16 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     const uint32_t mode = e->opt.collision_mode;
     if (mode == SB_COLLIDE_GRID && e->P) {
         // (re)build the spatial hash from the READ state when the displacement bound demands it
-        uint32_t *counts = const_cast<uint32_t *>(e->grid.cell_scan);
-        uint32_t *boff = const_cast<uint32_t *>(e->grid.block_off);
-        const uint32_t n = e->ncell + 1, nblocks = cdiv(n, SB_SCAN_BLOCK);
-        k_grid_decide<<<1, 1, 0, e->stream>>>(e->d_grid_ctl);
-        k_grid_zero<<<std::min(cdiv(n, SB_BLOCK), 2048u), SB_BLOCK, 0, e->stream>>>(counts, n, e->d_grid_ctl);
-        k_grid_count<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(r.pos, e->P, e->grid, counts, e->d_cell_of,
-                                                                     e->d_rank, e->d_grid_ctl);
-        k_grid_scan_blocks<<<nblocks, SB_BLOCK, 0, e->stream>>>(counts, n, boff, e->d_grid_ctl);
-        k_grid_scan_sums<<<1, SB_BLOCK, 0, e->stream>>>(boff, nblocks, e->d_grid_ctl);
-        k_grid_scatter<<<cdiv(e->P, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->d_pslot, e->P, e->grid, e->d_rank, e->d_rec,
-                                                                       e->d_grid_ctl);
+        const uint32_t n = e->ncell + 1, nblocks = cdiv(n, SB_SCAN_BLOCK), pb = cdiv(e->P, SB_BLOCK);
+        k_grid_decide<<<1, SB_BLOCK, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max, e->path == SB_PATH_TILED ? e->ntiles : pb);
+        k_grid_count<<<pb, SB_BLOCK, 0, e->stream>>>(r.pos, e->P, e->grid, e->d_cell_cnt, e->d_cell_of, e->d_rank,
+                                                     e->d_grid_ctl);
+        k_grid_scan_blocks<<<nblocks, SB_BLOCK, 0, e->stream>>>(e->d_cell_cnt, e->d_cell_scan, n, e->d_block_off,
+                                                                e->d_grid_ctl);
+        k_grid_scan_sums<<<1, SB_BLOCK, 0, e->stream>>>(e->d_block_off, nblocks, e->d_grid_ctl);
+        k_grid_scatter<<<pb, SB_BLOCK, 0, e->stream>>>(r.pos, e->d_pslot, e->P, e->d_cell_of, e->d_cell_scan,
+                                                       e->d_block_off, e->d_rank, e->d_rec, e->d_cell_start, n,
+                                                       e->d_grid_ctl);
     }
     if (e->path == SB_PATH_ATOMIC) {
         if (e->nbeam)
@@ -525,7 +567,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
                                                                                e->d_forces, e->d_broken);
         if (e->P) {
             dim3 g(cdiv(e->P, SB_BLOCK));
-#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, e->d_grid_ctl)
+#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, e->d_blk_max)
             if (mode == SB_COLLIDE_ALLPAIRS) SB_LAUNCH_P(SB_COLLIDE_ALLPAIRS);
             else if (mode == SB_COLLIDE_GRID) SB_LAUNCH_P(SB_COLLIDE_GRID);
             else SB_LAUNCH_P(SB_COLLIDE_OFF);
@@ -535,7 +577,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
         e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
-        e->d_grid_ctl, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+        e->d_blk_max, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
 #define SB_LAUNCH_TA(M, T) do { if (write_aux) SB_LAUNCH_T(M, T, true); else SB_LAUNCH_T(M, T, false); } while (0)
 #define SB_LAUNCH_TM(M) do { if (e->mat_mode == 2) SB_LAUNCH_TA(M, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(M, 1); else SB_LAUNCH_TA(M, 0); } while (0)
         if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(SB_COLLIDE_GRID);

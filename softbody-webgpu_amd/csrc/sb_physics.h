@@ -230,36 +230,49 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
 // SUPERSET of the interacting pairs of compute.wgsl:144-170 wherever the particles are (clamping
 // only piles far-away particles into edge cells: slower, never wrong).
 struct SbGrid {
-    const uint32_t *cell_scan; // per cell: exclusive scan inside its 2048-cell block
-    const uint32_t *block_off; // per 2048-cell block: offset of the block
-    const uint2 *rec;          // sorted by cell: {slot, internal index}
-    const uint32_t *cell_of;   // per particle: its cell at the last rebuild
-    float x0, y0, cell;
+    const uint32_t *cell_start; // per cell (+1 spare entry): absolute index of its first record
+    const float4 *rec;          // sorted by cell: {x, y AT BUILD TIME, bits(slot), bits(internal index)}
+    const uint32_t *cell_of;    // per particle: its cell at the last build
+    float x0, y0, cell, skin;
     uint32_t nx, ny;
 };
-// The hash is rebuilt only when needed: cells are 2r*(1+1/64) + 2*skin wide, and a rebuild happens as
-// soon as the sum of per-substep maximum displacements since the last build exceeds skin.  Until then
-// every particle is within skin of where it was binned, so two particles closer than 2r NOW were closer
-// than 2r + 2*skin THEN and sit in the same or adjacent cells of the (stale) binning: still a superset.
-// Candidates are therefore looked up in the cells of the last build but tested at their CURRENT positions.
+// The hash is rebuilt only when needed.  Cells are 2r*(1+1/64) + 2*skin wide; the engine keeps a bound
+// D on how far any particle can have moved since the last build (the sum of the per-substep maximum
+// displacements) and rebuilds before a substep whose READ state has D > skin.  While D <= skin, two
+// particles closer than 2r NOW were closer than 2r + 2*skin AT BUILD TIME and sit in the same or
+// adjacent cells of the stale binning (still a superset of the contacts), and a candidate whose
+// build-time position is farther than 2r + skin from the querying particle's current position
+// cannot be in contact: candidates are found in the stale cells, pre-filtered on their stale
+// positions and tested exactly at their CURRENT positions.
 struct SbGridCtl {
-    uint32_t rebuild;     // 1 while the build kernels of this substep must run
-    uint32_t force;       // set by the host (upload, halo unpack): rebuild unconditionally
-    uint32_t step_max;    // float bits: max displacement of any particle in the substep just run
-    float accum;          // sum of step maxima since the last build
+    uint32_t rebuild; // 1: the build kernels of this substep must run (written by k_grid_decide)
+    uint32_t force;   // set by the host (upload, halo unpack): rebuild unconditionally
+    float accum;      // D for the READ state of the coming substep
     float skin;
-    uint32_t builds;      // statistics
+    uint32_t builds;  // statistics
 };
 #define SB_SCAN_BLOCK 2048u
+#define SB_MAX_WAVES 16
+#define SB_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SB_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// largest displacement of any particle in this substep -> ctl->step_max (positive float bits order
-// like unsigned integers; anything not provably small, NaN included, reads as "huge")
-SB_DEV void sb_track_displacement(SbGridCtl *ctl, float m)
+// End of the particle kernel, called by EVERY thread of the block: this block's largest displacement
+// goes to blk_max[blockIdx.x] (float bits; anything not provably small, NaN included, reads as huge).
+// One plain slot per workgroup: funnelling ~1000 workgroups through atomics on one address cost
+// ~50 us per launch (same-address atomics retire one per ~12 ns).  k_grid_decide reduces the slots.
+SB_DEV void sb_store_block_displacement(uint32_t *blk_max, float m)
 {
+    __shared__ float s_wave_max[SB_MAX_WAVES];
     m = (m < 1.0e30f) ? m : 1.0e30f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63u) == 0u && m > 0.0f) atomicMax(&ctl->step_max, __float_as_uint(m));
+    if ((threadIdx.x & 63u) == 0u) s_wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = 0.0f;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) b = fmaxf(b, s_wave_max[w]);
+        SB_AGENT_STORE(&blk_max[blockIdx.x], __float_as_uint(b));
+    }
 }
 
 SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
@@ -269,33 +282,40 @@ SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
     if (q >= (float)n) return n - 1u;
     return (uint32_t)q;
 }
-SB_DEV uint32_t sb_grid_start(const SbGrid &g, uint32_t c) { return g.cell_scan[c] + g.block_off[c / SB_SCAN_BLOCK]; }
+
+// record ranges of the three cell rows around a (stale) cell
+struct SbGridRanges {
+    uint32_t b[3], e[3];
+};
+SB_DEV SbGridRanges sb_grid_ranges(const SbGrid &g, uint32_t cell)
+{
+    SbGridRanges rg;
+    const uint32_t cx = cell % g.nx, cy = cell / g.nx;
+    const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < g.nx ? cx + 1u : g.nx - 1u;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int yy = (int)cy + r - 1;
+        const bool in = yy >= 0 && yy < (int)g.ny;
+        const uint32_t row = in ? (uint32_t)yy * g.nx : 0u;
+        const uint32_t b = g.cell_start[row + xa], e = g.cell_start[row + xb + 1u]; // one spare entry at the end
+        rg.b[r] = in ? b : 0u;
+        rg.e[r] = in ? e : 0u;
+    }
+    return rg;
+}
 
 // The collision loop of compute.wgsl:144-170 restricted to the 3x3 cell neighbourhood, applying
 // contacts in ASCENDING SLOT ORDER exactly like the all-pairs scan does: repeatedly pick the
 // contact with the smallest slot above the last one applied.  Non-contacts are no-ops in the
 // reference loop, so skipping them changes nothing; the result is bit-identical to all-pairs.
-SB_DEV void sb_collide_grid(const SbGrid &g, const SbParams &prm, float friction, float elasticity_coeff,
-                            SbParticle &particle, const SbParticle &self, uint32_t i,
+SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbParams &prm, float friction,
+                            float elasticity_coeff, SbParticle &particle, const SbParticle &self, uint32_t i,
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
                             const float2 *__restrict__ vel_r)
 {
     const float two_r = prm.particle_radius * 2.0f;
     const float far2 = two_r * two_r * 1.001f;
-    const uint32_t cell = g.cell_of[i]; // where this particle was binned at the last rebuild
-    const uint32_t cx = cell % g.nx, cy = cell / g.nx;
-    const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < g.nx ? cx + 1u : g.nx - 1u;
-    uint32_t rb[3], re[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        int yy = (int)cy + r - 1;
-        if (yy < 0 || yy >= (int)g.ny) {
-            rb[r] = re[r] = 0u;
-        } else {
-            rb[r] = sb_grid_start(g, (uint32_t)yy * g.nx + xa);
-            re[r] = sb_grid_start(g, (uint32_t)yy * g.nx + xb + 1u); // cell array has one spare entry
-        }
-    }
+    const float reach = two_r + g.skin, stale_far2 = reach * reach * 1.001f;
     bool have_last = false;
     uint32_t last = 0u;
     for (;;) {
@@ -303,21 +323,30 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbParams &prm, float friction
         float2 best_p = make_float2(0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            for (uint32_t k = rb[r]; k < re[r]; k++) {
-                const uint2 rec = g.rec[k];
-                const uint32_t slot = rec.x, id = rec.y;
-                if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
-                const float2 q = pos_r[id];
-                const float ex = q.x - self.p.x, ey = q.y - self.p.y;
-                const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
-                // sqrt is monotone: d2 clearly above (2r)^2 cannot give d < 2r (and is not 0), so the
-                // correctly rounded root is only evaluated for the few candidates near contact range
-                if (d2 > far2) continue;
-                const float d = sb_sqrt(d2);
-                if (d == 0.0f || d < two_r) {
-                    best_slot = slot;
-                    best_id = id;
-                    best_p = q;
+            for (uint32_t k0 = rg.b[r]; k0 < rg.e[r]; k0 += 4u) {
+                float4 rc[4]; // records are consecutive: fetch four at a time, then test
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    rc[j] = (k0 + (uint32_t)j < rg.e[r]) ? g.rec[k0 + (uint32_t)j]
+                                                         : make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t slot = __float_as_uint(rc[j].z), id = __float_as_uint(rc[j].w);
+                    if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
+                    const float sx = rc[j].x - self.p.x, sy = rc[j].y - self.p.y;
+                    if (sx * sx + sy * sy > stale_far2) continue; // cannot have come within 2r (see SbGrid)
+                    const float2 q = pos_r[id];
+                    const float ex = q.x - self.p.x, ey = q.y - self.p.y;
+                    const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
+                    // sqrt is monotone: d2 clearly above (2r)^2 cannot give d < 2r (and is not 0), so the
+                    // correctly rounded root is only evaluated for the few candidates near contact range
+                    if (d2 > far2) continue;
+                    const float d = sb_sqrt(d2);
+                    if (d == 0.0f || d < two_r) {
+                        best_slot = slot;
+                        best_id = id;
+                        best_p = q;
+                    }
                 }
             }
         }
