@@ -192,6 +192,10 @@ def main():
             if tr:
                 roof["traffic"] = tr[0]
                 roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
+                # the kernel moves far fewer bytes than the algorithmic figure (dictionary-coded beam
+                # parameters, outputs stored lazily, zero accelerations skipped): say how busy HBM really is
+                roof["physical_GBps"] = tr[0] / (roof["avg_launch_us"] * 1e-6) / 1e9
+                roof["physical_frac"] = roof["physical_GBps"] / HBM_PEAK_GBS
         line = {
             "metric": "particle-steps/sec", "value": P_total * a.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,

@@ -17,5 +17,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || { echo pmc write failed; tail -5 $OUT/pmc_write.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- $OLDPWD/tools/hbm_calib > $OUT/calib_fetch.log 2>&1 || { echo calib fetch failed; tail -5 $OUT/calib_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calib_write -- $OLDPWD/tools/hbm_calib > $OUT/calib_write.log 2>&1 || { echo calib write failed; tail -5 $OUT/calib_write.log; exit 1; }
-find $OUT -name "*.csv" | head -30
+# config 3 (grid collisions): bench line + kernel trace
+python3 $OLDPWD/bench.py --collisions grid --no-cpu-baseline > $OUT/bench_grid.json 2> $OUT/bench_grid.err || { echo grid bench failed; tail -5 $OUT/bench_grid.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grid -- python3 $OLDPWD/bench.py --collisions grid --steps 200 --warmup 16 --no-cpu-baseline > $OUT/trace_grid.log 2>&1 || { echo grid trace failed; exit 1; }
+find $OUT -name "*.csv" | wc -l
 du -sh $OUT

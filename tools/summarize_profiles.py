@@ -42,6 +42,17 @@ if os.path.exists(bj):
     shutil.copy(bj, os.path.join(dst, "%s_bench.json" % tag))
     summary["bench"] = json.loads(open(bj).read().strip().splitlines()[-1])
 
+kg = one("trace_grid/*/*_kernel_stats.csv")
+if kg:
+    shutil.copy(kg, os.path.join(dst, "%s_grid_kernel_stats.csv" % tag))
+    summary["grid_kernel_stats"] = [{"name": r["Name"].split("(")[0], "calls": int(r["Calls"]),
+                                     "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
+                                    for r in csv.DictReader(open(kg))]
+bg = os.path.join(src, "bench_grid.json")
+if os.path.exists(bg):
+    shutil.copy(bg, os.path.join(dst, "%s_bench_grid.json" % tag))
+    summary["bench_grid"] = json.loads(open(bg).read().strip().splitlines()[-1])
+
 calib = {}
 for which, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
     for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
