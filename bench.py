@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--collisions", choices=["off", "grid"], default="off")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
-    ap.add_argument("--ghost-depth", type=int, default=16,
+    ap.add_argument("--ghost-depth", type=int, default=32,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
     ap.add_argument("--grid-skin", type=float, default=0.0, help="spatial-hash skin (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,7 +104,6 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
-    import numpy as np
     import torch
     import __graft_entry__ as ge
     sb = ge.load_package()

@@ -473,8 +473,10 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
         e->grid.skin = skin;
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
-    SB_TRY(dev_alloc(e, &e->d_forces, P));
-    SB_HIP(e, hipMemset(e->d_forces, 0, std::max<size_t>(P, 1) * sizeof(int2)));
+    if (e->path == SB_PATH_ATOMIC) {
+        SB_TRY(dev_alloc(e, &e->d_forces, P));
+        SB_HIP(e, hipMemset(e->d_forces, 0, std::max<size_t>(P, 1) * sizeof(int2)));
+    }
     SB_TRY(dev_alloc(e, &e->d_broken, (nc + 31) / 32));
     SB_HIP(e, hipMemset(e->d_broken, 0, std::max<size_t>((nc + 31) / 32, 1) * 4));
     SB_TRY(dev_alloc(e, &e->d_dead_gen, B));

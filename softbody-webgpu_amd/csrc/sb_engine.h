@@ -60,7 +60,6 @@ struct sb_engine {
     uint32_t *d_broken = nullptr;  // bit per beam copy: flagged this frame (compute.wgsl:86-88)
     uint32_t *d_dead_gen = nullptr;  // per beam slot: number of the delete pass that removed it (0 = live)
     uint32_t delete_gen = 0;
-    uint32_t *d_flags = nullptr;   // [0] = any beam flagged since the last delete pass
     // halo exchange lists (internal particle indices; beam copy indices)
     uint32_t *d_ghost_p = nullptr, *d_send_p = nullptr;
     uint32_t n_ghost_p = 0, n_send_p = 0;
