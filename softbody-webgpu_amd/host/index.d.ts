@@ -196,6 +196,9 @@ export function addRectangle(mapper: BufferMapper, ids: { particleId: number, be
     d: number, w: number, h: number, spring: number, damp: number, yieldStrain: number, strainLimit: number,
     antiDiagonal?: boolean): { particleId: number, beamId: number };
 export function defaultScene(mapper: BufferMapper): BufferMapper;
+/** fills the mapper's ArrayBuffers directly (no object model): w x h lattice, ~3 beams per particle */
+export function fillLattice(mapper: BufferMapper, ox: number, oy: number, d: number, w: number, h: number, spring: number,
+    damp: number, yieldStrain: number, strainLimit: number, jitter?: ((k: number) => number) | null): { particles: number, beams: number };
 
 export const COLLIDE: { readonly OFF: 0, readonly ALLPAIRS: 1, readonly GRID: 2 };
 export const PATH: { readonly AUTO: 0, readonly ATOMIC: 1, readonly TILED: 2 };

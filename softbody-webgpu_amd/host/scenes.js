@@ -43,3 +43,48 @@ function defaultScene(mapper) {
 }
 
 module.exports = { addRectangle, defaultScene };
+
+/**
+ * Fast path for big lattices: fills the BufferMapper's ArrayBuffers directly (identity mapping, what
+ * writeState() would produce) without creating millions of Particle/Beam objects.  Same topology and
+ * emission order as addRectangle with antiDiagonal=false (BASELINE config 2: ~3 beams per particle).
+ * `jitter(k)` returns a displacement for coordinate k = 2*index + {0,1} (default: none).
+ */
+function fillLattice(mapper, ox, oy, d, w, h, spring, damp, yieldStrain, strainLimit, jitter) {
+    const P = w * h, B = (h - 1) * w + (w - 1) * h + (w - 1) * (h - 1);
+    if (P > mapper.maxParticles || B > mapper.maxBeams) throw new RangeError('lattice exceeds the mapper capacity');
+    const lay = mapper.layout;
+    const pf = new Float32Array(mapper.particleData);
+    const map = new DataView(mapper.mapping);
+    const bd = new DataView(mapper.beamData);
+    const setIndex = lay.indexBytes === 2 ? (o, v) => map.setUint16(o * 2, v, true) : (o, v) => map.setUint32(o * 4, v, true);
+    const diag = Math.SQRT2 * d;
+    let j = 0;
+    const beam = (a, b, len) => {
+        const o = j * lay.beamStride;
+        if (lay.indexBytes === 2) { bd.setUint16(o, a, true); bd.setUint16(o + 2, b, true); } else { bd.setUint32(o, a, true); bd.setUint32(o + 4, b, true); }
+        const f = o + lay.beamFloatBase;
+        bd.setFloat32(f, len, true); bd.setFloat32(f + 4, len, true); bd.setFloat32(f + 8, len, true);
+        bd.setFloat32(f + 12, spring, true); bd.setFloat32(f + 16, damp, true);
+        bd.setFloat32(f + 20, yieldStrain, true); bd.setFloat32(f + 24, strainLimit, true);
+        setIndex(mapper.maxParticles + j, j);
+        j++;
+    };
+    for (let x = 0; x < w; x++) {
+        for (let y = 0; y < h; y++) {
+            const i = x * h + y;
+            pf[i * 6] = x * d + ox + (jitter ? jitter(2 * i) : 0);
+            pf[i * 6 + 1] = y * d + oy + (jitter ? jitter(2 * i + 1) : 0);
+            setIndex(i, i);
+            const up = y < h - 1, right = x < w - 1;
+            if (up) beam(i, i + 1, d);
+            if (right) beam(i, i + h, d);
+            if (up && right) beam(i, i + h + 1, diag);
+        }
+    }
+    mapper.meta.particleCount = P;
+    mapper.meta.beamCount = B;
+    return { particles: P, beams: B };
+}
+
+module.exports.fillLattice = fillLattice;

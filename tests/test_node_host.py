@@ -38,3 +38,17 @@ def test_js_host_gpu_end_to_end():
     1000 substeps of the config-1 lattice through the worker API."""
     r = run_node("gpu.test.js")
     assert r["ok"] and r["info"]["path"] == 2 and r["info"]["tiles"] >= 4
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_bench_small():
+    """host/bench.js (config-2 generator + timed stepping through the addon) on a small lattice."""
+    import __graft_entry__ as ge
+    ge.build()
+    p = subprocess.run(["node", os.path.join(ROOT, "softbody-webgpu_amd", "host", "bench.js"), "--width", "64",
+                        "--height", "48", "--steps", "64", "--warmup", "8"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["particles"] == 64 * 48 and r["info"]["path"] == 2 and r["particle_steps_per_s_device"] > 0
+    assert r["first_particle_y"] < 1000.0
