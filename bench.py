@@ -36,13 +36,16 @@ def parse():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ghost-depth", type=int, default=32,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
+    ap.add_argument("--subticks", type=int, default=64)
+    ap.add_argument("--mixed-stiffness", action="store_true",
+                    help="BASELINE config 5: springs drawn from {1,3,50,500}, use with --subticks 128")
     ap.add_argument("--grid-skin", type=float, default=0.0, help="spatial-hash skin (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
 
 
-def cpu_baseline(sb, buf, bounds, mode, budget_s):
+def cpu_baseline(sb, buf, bounds, mode, budget_s, subticks=64):
     """Times the oracle (our C restatement of compute.wgsl; the reference has no CPU path) on
     the same scene for a bounded number of substeps.  Reported beside the GPU, never the target."""
     import __graft_entry__ as ge
@@ -53,7 +56,7 @@ def cpu_baseline(sb, buf, bounds, mode, budget_s):
     P = buf.particle_count
     out = {}
     for label, threads, share in (("single", 1, 0.35), ("all", cores, 0.65)):
-        ref = orc.OracleEngine(bounds, 10.0, 64, buf.layout, mode, threads=threads)
+        ref = orc.OracleEngine(bounds, 10.0, subticks, buf.layout, mode, threads=threads)
         ref.write_buffers(buf)
         t0 = time.perf_counter()
         ref.step(2)
@@ -130,9 +133,13 @@ def main():
     else:
         buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0,
                                     depth=a.ghost_depth)
+    if a.mixed_stiffness:
+        if plan is not None:
+            sys.exit("--mixed-stiffness is a single-GPU option (slab scenes draw per-rank beam lists)")
+        sb.scenes.mix_stiffness(buf, subticks=a.subticks)
     P_local = buf.particle_count if plan is None else plan.n_owned
     B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
-    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=64, layout=2,
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
                     path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin)
     eng.write_buffers(buf)
@@ -171,8 +178,9 @@ def main():
 
     if rank == 0:
         workload = ("BASELINE config 2: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
-                    "spring 50 damp 700, jitter 1.0, subticks 64, collisions %s, v2 (u32) layout"
-                    % (W, H, P_local, B_local, a.collisions))
+                    "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout"
+                    % (W, H, P_local, B_local, "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else
+                       "spring 50 damp 700", a.subticks, a.collisions))
         copies = eng.info("beam_copies")
         alg_bytes = 52.0 * B_local + 48.0 * P_local  # per substep, one launch
         roof = None
@@ -209,7 +217,7 @@ def main():
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(sb, buf, bounds, mode, a.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(sb, buf, bounds, mode, a.cpu_seconds, a.subticks)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -116,3 +116,17 @@ def hash_uniform(seed, n):
         x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         x = x ^ (x >> np.uint64(31))
     return (x >> np.uint64(11)).astype(np.float64) / float(1 << 52) - 1.0
+
+
+def mix_stiffness(buf, seed=1, subticks=128):
+    """BASELINE config 5: per-beam spring drawn from {1, 3, 50, 500} (the values in main.ts:218-246)
+    with damping scaled so that the explicit integrator stays inside its stability envelope at
+    dt = 1/subticks (per-node sum of damp*dt^2 <~ 0.5 with ~6 beams per node)."""
+    B = buf.beam_count
+    pick = ((hash_uniform(seed + 77, B) + 1.0) * 2.0).astype(np.int64).clip(0, 3)
+    springs = np.array([1.0, 3.0, 50.0, 500.0], dtype="<f4")[pick]
+    damp_cap = np.float32(0.5 / 6.0 * subticks * subticks)       # damp * dt^2 * 6 beams <= 0.5
+    damps = np.minimum(springs * np.float32(14.0), damp_cap).astype("<f4")
+    buf.beams["spring"][:B] = springs
+    buf.beams["damp"][:B] = damps
+    return buf

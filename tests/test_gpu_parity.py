@@ -316,3 +316,16 @@ def test_user_input_changes_between_frames(sb, oracle):
         got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
         assert_same(got, exp, "frame %d" % k)
     eng.destroy()
+
+
+def test_mixed_stiffness_substepped(sb, oracle):
+    """BASELINE config 5 in small: per-beam springs from {1, 3, 50, 500} (8 dictionary rows with the two
+    rest lengths), 128 subticks, dropped on the floor; bit-exact over 3 frames on both schedules."""
+    buf = sb.scenes.lattice_buffers(40, 40, d=30.0, origin=(60.0, 12.0), jitter=1.0, layout=2, velocity=(0.5, -2.0),
+                                    strain_limit=0.8)
+    sb.scenes.mix_stiffness(buf, subticks=128)
+    assert len(set(buf.beams["spring"][:buf.beam_count].tolist())) == 4
+    for path in (ATOMIC, TILED):
+        got, exp, _ = run_both(sb, oracle, buf, frames=3, mode=OFF, path=path, bounds=4000.0, subticks=127, tile=256)
+        assert np.isfinite(exp.particles).all()
+        assert_same(got, exp, "mixed stiffness path %d" % path)
