@@ -204,3 +204,6 @@ export const COLLIDE: { readonly OFF: 0, readonly ALLPAIRS: 1, readonly GRID: 2 
 export const PATH: { readonly AUTO: 0, readonly ATOMIC: 1, readonly TILED: 2 };
 /** the raw N-API addon (csrc/sb_napi.c); throws if the addon or the HIP library is missing */
 export function native(): Record<string, (...args: unknown[]) => unknown>;
+
+/** headless software renderer of render.wgsl's picture (debugging only): binary PPM (P6) */
+export function renderPPM(mapper: BufferMapper, opts?: { boundsSize?: number, particleRadius?: number, resolution?: number }): Buffer;

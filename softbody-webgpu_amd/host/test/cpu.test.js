@@ -112,5 +112,17 @@ const same = (ab, file) => Buffer.compare(Buffer.from(ab), fs.readFileSync(path.
             assert.throws(() => new h.WGPUSoftbodyEngine({}), /no CPU fallback/);
         }
     });
+    test('headless renderer draws discs and stress-coloured beams (render.wgsl:42-54,82)', () => {
+        const m = h.defaultScene(new h.BufferMapper(1 << 27));
+        m.writeState();
+        const ppm = h.renderPPM(m, { resolution: 500 });
+        assert.strictEqual(ppm.slice(0, 15).toString('ascii'), 'P6\n500 500\n255\n');
+        const px = (x, y) => { const k = 15 + ((499 - y) * 500 + x) * 3; return [ppm[k], ppm[k + 1], ppm[k + 2]]; };
+        // free particle at (925, 10) (main.ts:222), 2 px per unit: inner colour slightly off the centre
+        assert.deepStrictEqual(px(463, 6), [0, 89, 128]);
+        // beam 0 joins particles (185,10)-(185,70): stress = strain = 0 -> (1,1,1) on the line between the discs
+        assert.deepStrictEqual(px(92, 20), [255, 255, 255]);
+        assert.deepStrictEqual(px(300, 300), [0, 0, 0]);
+    });
     console.log(JSON.stringify({ passed: results.length, failed: process.exitCode ? 1 : 0, names: results }));
 })();

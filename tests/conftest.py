@@ -16,6 +16,7 @@ def pytest_configure(config):
 def sb():
     """The product package (directory name has a hyphen, so it is loaded by path)."""
     import __graft_entry__ as ge
+    ge.build()  # make is a no-op when the in-tree .so files are current; a fresh checkout gets them built
     return ge.load_package()
 
 
