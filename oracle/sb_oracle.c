@@ -8,7 +8,9 @@
  * it.  WGSL built-ins are pinned to these definitions (the WGSL spec only
  * bounds them in ULP, so any of them is a valid reference outcome):
  *   length(v)    = sqrt(v.x*v.x + v.y*v.y)           (correctly rounded sqrt)
- *   normalize(v) = (v.x / length(v), v.y / length(v)) (correctly rounded div)
+ *   normalize(v) = (v.x * r, v.y * r), r = 1 / length(v)  (one correctly rounded reciprocal; real
+ *                  WebGPU back ends lower normalize to v * inverseSqrt(dot(v,v)), so the product
+ *                  form is at least as faithful as two divisions and costs one divide less)
  *   distance(a,b)= length(a - b)
  *   dot(a,b)     = a.x*b.x + a.y*b.y
  *   min(a,b)     = b < a ? b : a ;  max(a,b) = a < b ? b : a
@@ -48,8 +50,8 @@ static inline float v_length(v2 v) { return sqrtf(v.x * v.x + v.y * v.y); }
 static inline float v_dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
 static inline v2 v_normalize(v2 v)
 {
-    float l = v_length(v);
-    v2 r = { v.x / l, v.y / l };
+    float inv = 1.0f / v_length(v);
+    v2 r = { v.x * inv, v.y * inv };
     return r;
 }
 

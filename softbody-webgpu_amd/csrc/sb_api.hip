@@ -369,7 +369,7 @@ sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_b
             if (e->mat_mode) w |= mat_of_slot[tl.copy_slot[c]] << (2 * lbits);
             c_pair[c] = w;
         }
-        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_own * sizeof(int2) + (size_t)e->nmat * 5 * sizeof(float);
+        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_all * sizeof(int2) + (size_t)e->nmat * 5 * sizeof(float);
         if (e->lds_bytes > 160 * 1024)
             SB_FAIL(e, SB_ERR_UNSUPPORTED, "tile needs %zu bytes of LDS (> 160 KiB): lower tile_particles or use SB_PATH_ATOMIC", e->lds_bytes);
     } else {

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
     int *s_f = (int *)(s_pos + cap_all);
-    float *s_mat = (float *)(s_f + 2 * cap_own);
+    float *s_mat = (float *)(s_f + 2 * cap_all); // accumulators exist for halo slots too: their sums are never read
 
     const uint32_t tile = sb_tile_of_block(blockIdx.x, ntiles);
     const uint32_t p0 = tile_p0[tile], n_own = tile_p0[tile + 1] - p0;
@@ -182,8 +182,16 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         s_f[2 * i] = 0;
         s_f[2 * i + 1] = 0;
     }
-    if (has_halo) s_pos[n_own + tid] = hp;
-    for (uint32_t i = tid + SB_BLOCK; i < n_halo; i += SB_BLOCK) s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
+    if (has_halo) {
+        s_pos[n_own + tid] = hp;
+        s_f[2 * (n_own + tid)] = 0;
+        s_f[2 * (n_own + tid) + 1] = 0;
+    }
+    for (uint32_t i = tid + SB_BLOCK; i < n_halo; i += SB_BLOCK) {
+        s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
+        s_f[2 * (n_own + i)] = 0;
+        s_f[2 * (n_own + i) + 1] = 0;
+    }
     if (MAT != 0)
         for (uint32_t i = tid; i < nmat * 5u; i += SB_BLOCK) s_mat[i] = mat_tab[i];
     // SB_COLLIDE_GRID: the record ranges of each particle's three cell rows are fetched here, so the two
@@ -231,12 +239,12 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
                 const uint32_t la = word & lmask, lb = (word >> lbits) & lmask;
                 float length, spring, damp, yield, limit;
                 if (MAT != 0) {
-                    const float *m = s_mat + 5u * (word >> (2u * lbits));
-                    length = MAT == 2 ? m[0] : ln[u];
-                    spring = m[1];
-                    damp = m[2];
-                    yield = m[3];
-                    limit = m[4];
+                    const uint32_t m = 5u * (word >> (2u * lbits)); // 32-bit LDS index
+                    length = MAT == 2 ? s_mat[m] : ln[u];
+                    spring = s_mat[m + 1u];
+                    damp = s_mat[m + 2u];
+                    yield = s_mat[m + 3u];
+                    limit = s_mat[m + 4u];
                 } else {
                     length = ln[u];
                     spring = b.spring[c];
@@ -271,14 +279,12 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
 #if SB_ABLATE & 32 // diagnostic build: no LDS force accumulation
                 if (res.ax == 0x12345678) s_f[2 * la] = res.ay + res.bx + res.by;
 #else
-                if (la < n_own) {
-                    atomicAdd(&s_f[2 * la], res.ax);
-                    atomicAdd(&s_f[2 * la + 1], res.ay);
-                }
-                if (lb < n_own) {
-                    atomicAdd(&s_f[2 * lb], res.bx);
-                    atomicAdd(&s_f[2 * lb + 1], res.by);
-                }
+                // both endpoints unconditionally: a halo endpoint lands in an accumulator nobody reads,
+                // which is cheaper than two exec-mask branches per beam
+                atomicAdd(&s_f[2 * la], res.ax);
+                atomicAdd(&s_f[2 * la + 1], res.ay);
+                atomicAdd(&s_f[2 * lb], res.bx);
+                atomicAdd(&s_f[2 * lb + 1], res.by);
 #endif
                 if (res.broken) atomicOr(&broken[c >> 5], 1u << (c & 31));
             }

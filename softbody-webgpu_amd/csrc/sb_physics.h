@@ -165,7 +165,8 @@ SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float targe
         len = sb_length(0.0f, -1.0e-10f);     // folded at compile time, correctly rounded
     }
     float force_mag = (target_length - len) * spring + (last_length - len) * damp; // :110
-    float nx = sb_div(dx, len), ny = sb_div(dy, len); // normalize(diff)
+    const float inv_len = sb_div(1.0f, len);
+    float nx = dx * inv_len, ny = dy * inv_len; // normalize(diff) = diff * (1 / length(diff)), DESIGN.md 2
     float fx = force_mag * nx, fy = force_mag * ny;   // :111
     const float stretch = len - target_length;
     r.target_length = target_length;
@@ -206,7 +207,8 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
     if (dist == 0.0f) {             // :151-154
         particle.p.y += sb_sign((float)index - (float)other_index);
     } else if (dist < prm.particle_radius * 2.0f) { // :155
-        float nx = sb_div(dx, dist), ny = sb_div(dy, dist);   // :156
+        const float inv_dist = sb_div(1.0f, dist);
+        float nx = dx * inv_dist, ny = dy * inv_dist;         // :156
         float tx = -ny, ty = nx;                              // :157
         float ux = self.v.x - ov.x, uy = self.v.y - ov.y;     // :158
         float impulse_normal = elasticity_coeff * (ux * nx + uy * ny); // :159
@@ -367,7 +369,8 @@ SB_DEV void sb_particle_finish(const SbParams &prm, const SbConsts &c, SbParticl
     particle.a.y += c.gravity_y;
     float vl = sb_length(particle.v.x, particle.v.y);
     if (vl > 0.0f) { // :174-176
-        float nx = sb_div(particle.v.x, vl), ny = sb_div(particle.v.y, vl);
+        const float inv_vl = sb_div(1.0f, vl);
+        float nx = particle.v.x * inv_vl, ny = particle.v.y * inv_vl;
         float px = sb_pow(sb_abs(particle.v.x), c.drag_exp);
         float py = sb_pow(sb_abs(particle.v.y), c.drag_exp);
         particle.a.x -= c.drag_coeff * px * nx;

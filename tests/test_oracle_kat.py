@@ -95,9 +95,12 @@ def test_stretched_beam_force_and_fixed_point(sb, oracle):
     fm = f32(f32(f32(100) - f32(110)) * f32(2)) + f32(f32(f32(105) - f32(110)) * f32(3))
     assert fm == f32(-35)
     dt = f32(1) / f32(64)
-    fx_fixed = f32(np.int32(-35 * 65536)) / f32(65536)  # exact here
-    # A gets -force = +35 in x, B gets -35
-    assert out.particles[0, 2] == f32(f32(35) * dt) and out.particles[1, 2] == f32(fx_fixed * dt)
+    nx = f32(f32(110) * f32(f32(1) / f32(110)))        # normalize(v) = v * (1 / length(v)): 1 ulp below 1
+    fx = f32(fm * nx)                                   # force on B (toward A: negative x)
+    to_b = f32(np.int32(np.trunc(np.float64(f32(fx * f32(65536)))))) / f32(65536)
+    to_a = f32(np.int32(np.trunc(np.float64(f32(-fx * f32(65536)))))) / f32(65536)
+    assert to_a == -to_b and abs(float(to_b) + 35.0) < 1e-4
+    assert out.particles[0, 2] == f32(to_a * dt) and out.particles[1, 2] == f32(to_b * dt)
     b = out.beams[0]
     assert b["last_length"] == f32(110)
     assert b["stress"] == f32(fm * f32(f32(1) / f32(20)))          # :71,122
@@ -126,7 +129,7 @@ def test_zero_length_guard(sb, oracle):
     out, _ = run(oracle, buf, n=1, mode=0)
     ln = np.sqrt(f32(f32(0) * f32(0)) + f32(f32(-1e-10) * f32(-1e-10)), dtype=f32)
     fm = f32(f32(f32(100) - ln) * f32(1)) + f32(f32(f32(100) - ln) * f32(0))
-    ny = f32(f32(-1e-10) / ln)
+    ny = f32(f32(-1e-10) * f32(f32(1) / ln))   # normalize(v) = v * (1 / length(v))
     fy = f32(fm * ny)
     dt = f32(1) / f32(64)
     # A gets -force (so +y), B gets +force (-y)
@@ -242,8 +245,9 @@ def test_drag(sb, oracle):
     out, _ = run(oracle, buf, n=1)
     dt = f32(1) / f32(64)
     L = np.sqrt(f32(f32(9) + f32(16)), dtype=f32)
-    ax = f32(f32(0) - f32(f32(f32(0.001) * f32(9)) * f32(f32(3) / L)))
-    ay = f32(f32(0) - f32(f32(f32(0.001) * f32(16)) * f32(f32(-4) / L)))
+    inv = f32(f32(1) / L)   # normalize(v) = v * (1 / length(v))
+    ax = f32(f32(0) - f32(f32(f32(0.001) * f32(9)) * f32(f32(3) * inv)))
+    ay = f32(f32(0) - f32(f32(f32(0.001) * f32(16)) * f32(f32(-4) * inv)))
     assert out.particles[0, 2] == f32(f32(3) + f32(ax * dt))
     assert out.particles[0, 3] == f32(f32(-4) + f32(ay * dt))
 
