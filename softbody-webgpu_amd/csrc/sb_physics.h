@@ -123,6 +123,16 @@ SB_DEV double sb_exp2_d(double x)
     return s * p1 * p2;
 }
 
+// the general-exponent path is ~300 instructions of binary64 arithmetic that almost no scene runs
+// (drag_exp defaults to 2): kept out of line so it is not replicated into every unrolled call site
+__device__ __attribute__((noinline)) float sb_pow_general(float x, float y)
+{
+    const float inf = __uint_as_float(0x7f800000u);
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : inf);
+    if (x == inf) return (y > 0.0f) ? inf : ((y == 0.0f) ? 1.0f : 0.0f);
+    return (float)sb_exp2_d((double)y * sb_log2_d((double)x));
+}
+
 SB_DEV float sb_pow(float x, float y)
 {
     if (x != x || y != y) return x + y;
@@ -130,10 +140,7 @@ SB_DEV float sb_pow(float x, float y)
     if (y == 2.0f) return x * x;
     if (y == 3.0f) return x * x * x;
     if (y == 4.0f) return (x * x) * (x * x);
-    const float inf = __uint_as_float(0x7f800000u);
-    if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : inf);
-    if (x == inf) return (y > 0.0f) ? inf : ((y == 0.0f) ? 1.0f : 0.0f);
-    return (float)sb_exp2_d((double)y * sb_log2_d((double)x));
+    return sb_pow_general(x, y);
 }
 
 // ---------------------------------------------------------------- beam (compute.wgsl:103-130)
