@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <numeric>
+#include <stdexcept>
 #include <unordered_map>
 
 #include "sb_engine.h"
@@ -168,7 +170,7 @@ sb_status sb_destroy(sb_engine *e)
     return SB_OK;
 }
 
-sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_bytes, const void *mapping,
+static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_t metadata_bytes, const void *mapping,
                            size_t mapping_bytes, const void *particles, size_t particles_bytes,
                            const void *beams, size_t beams_bytes)
 {
@@ -593,7 +595,7 @@ sb_status sb_get_counts(sb_engine *e, uint32_t *particles, uint32_t *beams)
     return SB_OK;
 }
 
-sb_status sb_load_buffers(sb_engine *e, void *metadata, size_t metadata_bytes, void *mapping, size_t mapping_bytes,
+static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metadata_bytes, void *mapping, size_t mapping_bytes,
                           void *particles, size_t particles_bytes, void *beams, size_t beams_bytes)
 {
     if (!e) return SB_ERR_INVALID;
@@ -718,7 +720,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     return SB_OK;
 }
 
-sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_particles, uint32_t n_gp,
+static sb_status sb_halo_configure_impl(sb_engine *e, const uint32_t *ghost_particles, uint32_t n_gp,
                             const uint32_t *send_particles, uint32_t n_sp, const uint32_t *ghost_beams,
                             uint32_t n_gb, const uint32_t *send_beams, uint32_t n_sb)
 {
@@ -802,6 +804,41 @@ sb_status sb_get_stream(sb_engine *e, void **hip_stream)
     if (!e || !hip_stream) return SB_ERR_INVALID;
     *hip_stream = (void *)e->stream;
     return SB_OK;
+}
+
+// C++ exceptions must not cross the C boundary: the entry points that allocate host memory run
+// their bodies under a catch-all that turns std::bad_alloc (and anything else) into a status.
+#define SB_GUARDED(e, call)                                                                   \
+    try {                                                                                     \
+        return (call);                                                                        \
+    } catch (const std::bad_alloc &) {                                                        \
+        if (e) (e)->err = "out of host memory";                                               \
+        return SB_ERR_OOM;                                                                    \
+    } catch (const std::exception &ex) {                                                      \
+        if (e) (e)->err = std::string("internal error: ") + ex.what();                        \
+        return SB_ERR_INVALID;                                                                \
+    }
+
+sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_bytes, const void *mapping,
+                           size_t mapping_bytes, const void *particles, size_t particles_bytes,
+                           const void *beams, size_t beams_bytes)
+{
+    SB_GUARDED(e, sb_write_buffers_impl(e, metadata, metadata_bytes, mapping, mapping_bytes, particles, particles_bytes,
+                                        beams, beams_bytes))
+}
+
+sb_status sb_load_buffers(sb_engine *e, void *metadata, size_t metadata_bytes, void *mapping, size_t mapping_bytes,
+                          void *particles, size_t particles_bytes, void *beams, size_t beams_bytes)
+{
+    SB_GUARDED(e, sb_load_buffers_impl(e, metadata, metadata_bytes, mapping, mapping_bytes, particles, particles_bytes,
+                                       beams, beams_bytes))
+}
+
+sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_particles, uint32_t n_gp,
+                            const uint32_t *send_particles, uint32_t n_sp, const uint32_t *ghost_beams,
+                            uint32_t n_gb, const uint32_t *send_beams, uint32_t n_sb)
+{
+    SB_GUARDED(e, sb_halo_configure_impl(e, ghost_particles, n_gp, send_particles, n_sp, ghost_beams, n_gb, send_beams, n_sb))
 }
 
 } // extern "C"
