@@ -11,6 +11,8 @@
  *   normalize(v) = (v.x * r, v.y * r), r = 1 / length(v)  (one correctly rounded reciprocal; real
  *                  WebGPU back ends lower normalize to v * inverseSqrt(dot(v,v)), so the product
  *                  form is at least as faithful as two divisions and costs one divide less)
+ *   strain       = (len - target) * (1 / length)   (compute.wgsl:112; WGSL division is only 2.5-ULP
+ *                  accurate, the reciprocal of the constant rest length is one IEEE divide)
  *   distance(a,b)= length(a - b)
  *   dot(a,b)     = a.x*b.x + a.y*b.y
  *   min(a,b)     = b < a ? b : a ;  max(a,b) = a < b ? b : a
@@ -269,7 +271,7 @@ static void beam_update(const sbo_params *prm, const meta_t *md, const uint8_t *
     float force_mag = (target_length - len) * spring + (last_length - len) * damp;
     v2 n = v_normalize(diff);
     v2 force = { force_mag * n.x, force_mag * n.y };
-    float strain = (len - target_length) / length;
+    float strain = (len - target_length) * (1.0f / length); /* x / y pinned as x * (1/y), see header */
     /* :113-116 */
     if (f_abs(strain) > yield_strain) {
         target_length = len - yield_strain * length * f_sign(strain);

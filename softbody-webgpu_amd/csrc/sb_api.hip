@@ -352,6 +352,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
                     if (dict.size() >= mat_cap) { ok = false; break; }
                     it = dict.emplace(k, (uint32_t)dict.size()).first;
                     table.insert(table.end(), row, row + 5);
+                    table.push_back(mode == 2 ? 1.0f / row[0] : 0.0f); // 1 / length: one IEEE divide per material
                 }
                 mat_of_slot[s] = it->second;
             }
@@ -363,7 +364,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         }
         if (e->mat_mode == 0) lbits = 16;
         e->lbits = lbits;
-        e->nmat = (uint32_t)(mat_table.size() / 5);
+        e->nmat = (uint32_t)(mat_table.size() / 6);
         c_pair.assign(tl.copy_la.size(), 0xFFFFFFFFu);
         for (size_t c = 0; c < c_pair.size(); c++) {
             if (tl.copy_slot[c] == 0xFFFFFFFFu) continue;
@@ -371,7 +372,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             if (e->mat_mode) w |= mat_of_slot[tl.copy_slot[c]] << (2 * lbits);
             c_pair[c] = w;
         }
-        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_all * sizeof(int2) + (size_t)e->nmat * 5 * sizeof(float);
+        e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_all * sizeof(int2) + (size_t)e->nmat * 6 * sizeof(float);
         if (e->lds_bytes > 160 * 1024)
             SB_FAIL(e, SB_ERR_UNSUPPORTED, "tile needs %zu bytes of LDS (> 160 KiB): lower tile_particles or use SB_PATH_ATOMIC", e->lds_bytes);
     } else {

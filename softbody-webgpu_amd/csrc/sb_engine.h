@@ -81,7 +81,7 @@ struct sb_engine {
     uint32_t mat_mode = 0;    // 0: per-copy parameter arrays; 1: table of (spring,damp,yield,limit) + per-copy length;
                               // 2: table of (length,spring,damp,yield,limit)
     uint32_t nmat = 0;
-    float *d_mat = nullptr;   // [nmat][5] = length, spring, damp, yield_strain, strain_break_limit
+    float *d_mat = nullptr;   // [nmat][6] = length, spring, damp, yield_strain, strain_break_limit, 1/length
 
     // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state when the displacement bound demands it
     SbGrid grid{};

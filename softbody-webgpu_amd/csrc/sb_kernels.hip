@@ -16,6 +16,7 @@
 #define SB_ABLATE 0
 #endif
 #define SB_UNROLL 4
+#define SB_MAT_ROW 6u // length, spring, damp, yield, limit, 1/length
 
 // ---------------------------------------------------------------- SB_PATH_ATOMIC
 
@@ -28,8 +29,9 @@ __global__ __launch_bounds__(SB_BLOCK) void k_beams_atomic(SbBeamArrays b, uint3
     uint32_t ia = b.ia[i];
     if (ia == 0xFFFFFFFFu) return; // removed by a delete pass
     uint32_t ib = b.ib[i];
-    SbBeamResult r = sb_beam_eval<true>(pos[ia], pos[ib], b.length[i], b.target[i], b.last[i], b.spring[i],
-                                  b.damp[i], b.yield[i], b.limit[i]);
+    const float length = b.length[i];
+    SbBeamResult r = sb_beam_eval<true>(pos[ia], pos[ib], length, sb_div(1.0f, length), b.target[i], b.last[i],
+                                        b.spring[i], b.damp[i], b.yield[i], b.limit[i]);
     b.target[i] = r.target_length;
     b.last[i] = r.last_length;
     b.strain[i] = r.strain;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         s_f[2 * (n_own + i) + 1] = 0;
     }
     if (MAT != 0)
-        for (uint32_t i = tid; i < nmat * 5u; i += SB_BLOCK) s_mat[i] = mat_tab[i];
+        for (uint32_t i = tid; i < nmat * SB_MAT_ROW; i += SB_BLOCK) s_mat[i] = mat_tab[i];
     // SB_COLLIDE_GRID: the record ranges of each particle's three cell rows are fetched here, so the two
     // dependent lookups (particle -> stale cell -> cell starts) are long done when phase 2 needs them
     SbGridRanges rg[SB_UNROLL];
@@ -237,20 +239,22 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
             if (word != 0xFFFFFFFFu) { // padding, out of range, or removed by a delete pass
                 const uint32_t c = b0 + j0 + (uint32_t)u * SB_BLOCK;
                 const uint32_t la = word & lmask, lb = (word >> lbits) & lmask;
-                float length, spring, damp, yield, limit;
+                float length, inv_length, spring, damp, yield, limit;
                 if (MAT != 0) {
-                    const uint32_t m = 5u * (word >> (2u * lbits)); // 32-bit LDS index
+                    const uint32_t m = SB_MAT_ROW * (word >> (2u * lbits)); // 32-bit LDS index
                     length = MAT == 2 ? s_mat[m] : ln[u];
                     spring = s_mat[m + 1u];
                     damp = s_mat[m + 2u];
                     yield = s_mat[m + 3u];
                     limit = s_mat[m + 4u];
+                    inv_length = MAT == 2 ? s_mat[m + 5u] : sb_div(1.0f, length);
                 } else {
                     length = ln[u];
                     spring = b.spring[c];
                     damp = b.damp[c];
                     yield = b.yield[c];
                     limit = b.limit[c];
+                    inv_length = sb_div(1.0f, length);
                 }
                 const float target = tg[u];
 #if SB_ABLATE & 1 // diagnostic build: beam arithmetic replaced by a data-dependent dummy
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
                 {
                     float2 qa = s_pos[la], qb = s_pos[lb];
                     res.target_length = target;
-                    res.last_length = ls[u] + (qa.x - qb.x) * spring + length * damp + yield * limit;
+                    res.last_length = ls[u] + (qa.x - qb.x) * spring + length * damp + yield * limit + inv_length;
                     res.strain = res.stress = 0.f;
                     res.ax = __float_as_int(qa.y);
                     res.ay = __float_as_int(qb.y);
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
                     res.broken = false;
                 }
 #else
-                SbBeamResult res = sb_beam_eval<AUX>(s_pos[la], s_pos[lb], length, target, ls[u], spring, damp, yield, limit);
+                SbBeamResult res = sb_beam_eval<AUX>(s_pos[la], s_pos[lb], length, inv_length, target, ls[u], spring, damp,
+                                                     yield, limit);
 #endif
                 // target_length only moves on plastic yield (compute.wgsl:113-116): store it when it did
                 if (__float_as_uint(res.target_length) != __float_as_uint(target)) b.target[c] = res.target_length;
@@ -276,9 +281,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
                     b.strain[c] = res.strain;
                     b.stress[c] = res.stress;
                 }
-#if SB_ABLATE & 32 // diagnostic build: no LDS force accumulation
-                if (res.ax == 0x12345678) s_f[2 * la] = res.ay + res.bx + res.by;
-#else
+#if !(SB_ABLATE & 32) // diagnostic build: no LDS force accumulation
                 // both endpoints unconditionally: a halo endpoint lands in an accumulator nobody reads,
                 // which is cheaper than two exec-mask branches per beam
                 atomicAdd(&s_f[2 * la], res.ax);

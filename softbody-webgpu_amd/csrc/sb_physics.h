@@ -152,12 +152,13 @@ struct SbBeamResult {
 };
 
 // AUX = also produce strain/stress (compute.wgsl:122-123: outputs nobody reads before the caller
-// gets control back).  Without AUX the strain division is only executed for beams close to or
-// past their yield point: |len-target| <= 0.999*yield*length implies fl((len-target)/length) <= yield
-// for every input (the filter is conservative; NaN/inf/zero parameters fall through to the exact
-// path or agree with it), so the yield decision is bit-identical to evaluating :112-113 as written.
+// gets control back).  Branch-free (selects only): the kernels evaluate a batch of beams per thread
+// in straight-line code so the scheduler can interleave their dependency chains -- the IEEE sqrt and
+// reciprocal sequences are long serial chains, and a lone chain issues one VALU instruction every
+// ~4 cycles where interleaved chains issue one every 2.  inv_length = 1 / length (IEEE), computed
+// once per material at upload (or per beam when rest lengths are not in the table).
 template <bool AUX>
-SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float target_length,
+SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float inv_length, float target_length,
                                  float last_length, float spring, float damp, float yield_strain,
                                  float strain_break_limit)
 {
@@ -165,31 +166,22 @@ SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float targe
     const float beam_stress_scale = 1.0f / 20.0f; // :71
     SbBeamResult r;
     float dx = pb.x - pa.x, dy = pb.y - pa.y; // :103
-    float len = sb_length(dx, dy);            // :104 / :108 (same value unless the guard fires)
-    if (len == 0.0f) {                        // :104-107
-        dx = 0.0f;
-        dy = -1.0e-10f;
-        len = sb_length(0.0f, -1.0e-10f);     // folded at compile time, correctly rounded
-    }
-    float force_mag = (target_length - len) * spring + (last_length - len) * damp; // :110
+    const float len0 = sb_length(dx, dy);     // :104 / :108 (same value unless the guard fires)
+    const bool degenerate = len0 == 0.0f;     // :104-107
+    dx = degenerate ? 0.0f : dx;
+    dy = degenerate ? -1.0e-10f : dy;
+    const float len = degenerate ? sb_length(0.0f, -1.0e-10f) : len0; // constant folded, correctly rounded
+    const float force_mag = (target_length - len) * spring + (last_length - len) * damp; // :110
     const float inv_len = sb_div(1.0f, len);
-    float nx = dx * inv_len, ny = dy * inv_len; // normalize(diff) = diff * (1 / length(diff)), DESIGN.md 2
-    float fx = force_mag * nx, fy = force_mag * ny;   // :111
-    const float stretch = len - target_length;
-    r.target_length = target_length;
-    r.strain = 0.0f;
-    r.stress = 0.0f;
-    if (AUX || sb_abs(stretch) > yield_strain * length * 0.999f) {
-        float strain = sb_div(stretch, length);  // :112
-        if (sb_abs(strain) > yield_strain)       // :113-116
-            r.target_length = len - yield_strain * length * sb_sign(strain);
-        if (AUX) {
-            r.stress = force_mag * beam_stress_scale;        // :122
-            r.strain = sb_div(sb_abs(strain), yield_strain); // :123
-        }
-    }
+    const float nx = dx * inv_len, ny = dy * inv_len;     // normalize(diff) = diff * (1 / length(diff)), DESIGN.md 2
+    const float fx = force_mag * nx, fy = force_mag * ny; // :111
+    const float strain = (len - target_length) * inv_length; // :112, x / y pinned as x * (1 / y)
+    const float yielded_target = len - yield_strain * length * sb_sign(strain); // :115
+    r.target_length = (sb_abs(strain) > yield_strain) ? yielded_target : target_length; // :113-116
     r.broken = sb_abs(len - length) > length * strain_break_limit; // :117
-    r.last_length = len;                                           // :124
+    r.stress = AUX ? force_mag * beam_stress_scale : 0.0f;          // :122
+    r.strain = AUX ? sb_div(sb_abs(strain), yield_strain) : 0.0f;   // :123
+    r.last_length = len;                                            // :124
     const float sx = fx * particle_force_scale, sy = fy * particle_force_scale;
     r.bx = sb_f32_to_i32(sx);  // :129
     r.by = sb_f32_to_i32(sy);  // :130

@@ -104,7 +104,7 @@ def test_stretched_beam_force_and_fixed_point(sb, oracle):
     b = out.beams[0]
     assert b["last_length"] == f32(110)
     assert b["stress"] == f32(fm * f32(f32(1) / f32(20)))          # :71,122
-    assert b["strain"] == f32(f32(abs(f32(f32(10) / f32(100)))) / f32(0.5))  # :112,123
+    assert b["strain"] == f32(f32(abs(f32(f32(10) * f32(f32(1) / f32(100))))) / f32(0.5))  # :112 (x * (1/length)), :123
     assert b["target_length"] == f32(100)  # |strain|=0.1 <= yield 0.5
 
 
@@ -143,7 +143,7 @@ def test_yield_updates_target(sb, oracle):
     :123 strain_out uses the PRE-yield strain."""
     buf = mk(sb, [[100, 100, 0, 0, 0, 0], [250, 100, 0, 0, 0, 0]], [(0, 1, 100, 0, 0, 0.2, 10)], **NOFORCE)
     out, _ = run(oracle, buf, n=1)
-    strain = f32(f32(f32(150) - f32(100)) / f32(100))
+    strain = f32(f32(f32(150) - f32(100)) * f32(f32(1) / f32(100)))   # :112 as x * (1/length)
     assert out.beams[0]["target_length"] == f32(f32(150) - f32(f32(f32(0.2) * f32(100)) * f32(1)))
     assert out.beams[0]["strain"] == f32(strain / f32(0.2))
     # compression side
