@@ -15,7 +15,8 @@
 #ifndef SB_ABLATE
 #define SB_ABLATE 0
 #endif
-#define SB_UNROLL 4
+#define SB_TILE_BLOCK 512 // threads per tile workgroup: 8 waves (measured best: 256 x 4 20.6 us, 512 x 2 19.8 us, 1024 x 1 20.3 us)
+#define SB_UNROLL 2     // owned particles / beam copies each thread has in flight at a time
 #define SB_MAT_ROW 6u // length, spring, damp, yield, limit, 1/length
 
 // ---------------------------------------------------------------- SB_PATH_ATOMIC
@@ -126,7 +127,7 @@ SB_DEV uint32_t sb_tile_of_block(uint32_t b, uint32_t n)
 // (24 B read + 24 B written) + halo positions (8 B each, mostly L2 hits): the force
 // accumulator (compute.wgsl:68-69) never leaves the CU.
 template <int MODE, int MAT, bool AUX>
-__global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
+__global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
     SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
     const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
     const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits,
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
 
     // Phase 0.  Everything this workgroup will ever read from the particle arrays is requested
     // up front, back to back: the halo indices, the owned positions, and (for phase 2) the owned
-    // velocities and accelerations of the first SB_UNROLL x 256 particles.  The dependent halo
+    // velocities and accelerations of the first SB_UNROLL x SB_TILE_BLOCK particles.  The dependent halo
     // position gather goes out as soon as its indices are back.
     // acc_flag[buffer][tile] == 0 guarantees that every acceleration of the tile in that buffer IS
     // zero (true for almost every tile: compute.wgsl:188 zeroes a, only border friction :192,:196
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     float2 pp[SB_UNROLL], pv[SB_UNROLL], pa[SB_UNROLL];
 #pragma unroll
     for (int u = 0; u < SB_UNROLL; u++) {
-        const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+        const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
         if (i < n_own) {
             pp[u] = r.pos[p0 + i];
             pv[u] = r.vel[p0 + i];
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     if (has_halo) hp = r.pos[hidx];
 #pragma unroll
     for (int u = 0; u < SB_UNROLL; u++) {
-        const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+        const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
         if (i < n_own) {
             s_pos[i] = pp[u];
             s_f[2 * i] = 0;
             s_f[2 * i + 1] = 0;
         }
     }
-    for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK) { // tiles above 1024 particles
+    for (uint32_t i = tid + SB_UNROLL * SB_TILE_BLOCK; i < n_own; i += SB_TILE_BLOCK) { // tiles above 1024 particles
         s_pos[i] = r.pos[p0 + i];
         s_f[2 * i] = 0;
         s_f[2 * i + 1] = 0;
@@ -189,13 +190,13 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         s_f[2 * (n_own + tid)] = 0;
         s_f[2 * (n_own + tid) + 1] = 0;
     }
-    for (uint32_t i = tid + SB_BLOCK; i < n_halo; i += SB_BLOCK) {
+    for (uint32_t i = tid + SB_TILE_BLOCK; i < n_halo; i += SB_TILE_BLOCK) {
         s_pos[n_own + i] = r.pos[halo_idx[h0 + i]];
         s_f[2 * (n_own + i)] = 0;
         s_f[2 * (n_own + i) + 1] = 0;
     }
     if (MAT != 0)
-        for (uint32_t i = tid; i < nmat * SB_MAT_ROW; i += SB_BLOCK) s_mat[i] = mat_tab[i];
+        for (uint32_t i = tid; i < nmat * SB_MAT_ROW; i += SB_TILE_BLOCK) s_mat[i] = mat_tab[i];
     // SB_COLLIDE_GRID: the record ranges of each particle's three cell rows are fetched here, so the two
     // dependent lookups (particle -> stale cell -> cell starts) are long done when phase 2 needs them
     SbGridRanges rg[SB_UNROLL];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         uint32_t qcell[SB_UNROLL];
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
-            const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+            const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
             qcell[u] = grid.cell_of[p0 + (i < n_own ? i : 0u)];
         }
 #pragma unroll
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     }
     __syncthreads();
 
-    // Beam phase.  The slice is walked in batches of SB_UNROLL x 256 copies: all global loads of a
+    // Beam phase.  The slice is walked in batches of SB_UNROLL x SB_TILE_BLOCK copies: all global loads of a
     // batch are issued back to back (and the next batch's before this one is evaluated), so a wave
     // keeps ~2 x 3 x SB_UNROLL loads in flight instead of paying two dependent HBM latencies per beam.
     const uint32_t lmask = (1u << lbits) - 1u;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     auto fetch = [&](uint32_t j0, uint32_t *wo, float *to, float *lo, float *leno) {
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
-            const uint32_t j = j0 + (uint32_t)u * SB_BLOCK;
+            const uint32_t j = j0 + (uint32_t)u * SB_TILE_BLOCK;
             const bool ok = j < nb;
             const uint32_t cidx = b0 + (ok ? j : 0u);
             wo[u] = ok ? b.pair[cidx] : 0xFFFFFFFFu;
@@ -230,14 +231,14 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
         }
     };
     if (nb) fetch(tid, wd, tg, ls, ln);
-    for (uint32_t j0 = tid; j0 < nb + tid; j0 += SB_UNROLL * SB_BLOCK) {
-        const uint32_t jn = j0 + SB_UNROLL * SB_BLOCK;
+    for (uint32_t j0 = tid; j0 < nb + tid; j0 += SB_UNROLL * SB_TILE_BLOCK) {
+        const uint32_t jn = j0 + SB_UNROLL * SB_TILE_BLOCK;
         if (jn < nb + tid) fetch(jn, wn, tgn, lsn, lnn);
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
             const uint32_t word = wd[u];
             if (word != 0xFFFFFFFFu) { // padding, out of range, or removed by a delete pass
-                const uint32_t c = b0 + j0 + (uint32_t)u * SB_BLOCK;
+                const uint32_t c = b0 + j0 + (uint32_t)u * SB_TILE_BLOCK;
                 const uint32_t la = word & lmask, lb = (word >> lbits) & lmask;
                 float length, inv_length, spring, damp, yield, limit;
                 if (MAT != 0) {
@@ -335,10 +336,10 @@ __global__ __launch_bounds__(SB_BLOCK) void k_substep_tiled(
     };
 #pragma unroll
     for (int u = 0; u < SB_UNROLL; u++) {
-        const uint32_t i = tid + (uint32_t)u * SB_BLOCK;
+        const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
         if (i < n_own) finish(i, pv[u], pa[u], rg[u]);
     }
-    for (uint32_t i = tid + SB_UNROLL * SB_BLOCK; i < n_own; i += SB_BLOCK) {
+    for (uint32_t i = tid + SB_UNROLL * SB_TILE_BLOCK; i < n_own; i += SB_TILE_BLOCK) {
         SbGridRanges tail{};
         if (MODE == SB_COLLIDE_GRID) tail = sb_grid_ranges(grid, grid.cell_of[p0 + i]);
         finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f), tail);
@@ -583,7 +584,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #undef SB_LAUNCH_P
         }
     } else if (e->ntiles) {
-#define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_BLOCK, e->lds_bytes, e->stream>>>(            \
+#define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_TILE_BLOCK, e->lds_bytes, e->stream>>>(            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
         e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
         e->d_blk_max, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
