@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--subticks", type=int, default=64)
     ap.add_argument("--mixed-stiffness", action="store_true",
                     help="BASELINE config 5: springs drawn from {1,3,50,500}, use with --subticks 128")
+    ap.add_argument("--exchange", choices=["stream", "sync"], default="stream",
+                    help="N>1: RCCL exchange ordered on the engine stream (default) or host-synchronised")
     ap.add_argument("--grid-skin", type=float, default=0.0, help="spatial-hash skin (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
@@ -146,7 +148,8 @@ def main():
     if plan is None:
         stepper = eng.step
     else:
-        transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream())
+        transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream(),
+                                        ordered=a.exchange == "stream")
         stepper = halo.Exchanger(eng, plan, transport).step
 
     def barrier():
@@ -213,7 +216,8 @@ def main():
                        "tiles": eng.info("tiles"), "grid_builds": eng.info("grid_builds") if mode == 2 else None,
                        "parallelism": "single GPU" if world == 1 else
                        "%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, RCCL neighbour "
-                       "send/recv of ghost p,v,a + beam target/last every %d substeps" % (world, W, a.ghost_depth, a.ghost_depth)},
+                       "send/recv of ghost p,v,a + beam target/last every %d substeps (%s)"
+                       % (world, W, a.ghost_depth, a.ghost_depth, transport.mode)},
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:

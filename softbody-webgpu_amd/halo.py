@@ -169,15 +169,20 @@ class Exchanger:
 
 
 class TorchTransport:
-    """Neighbour exchange over torch.distributed.  On GPU the P2P ops are issued while the
-    engine's own HIP stream is torch's current stream, so RCCL waits for the pack kernel and the
-    unpack kernel waits for RCCL, all device-side: no host synchronisation per exchange."""
+    """Neighbour exchange over torch.distributed.  On GPU (`ordered=True`) the P2P ops are issued while
+    the engine's own HIP stream is torch's current stream, so RCCL waits for the pack kernel and the
+    unpack kernel waits for RCCL, all device-side: no host synchronisation per exchange.  If that
+    stream-ordered form raises on the first exchange, the transport drops to the conservative form
+    (drain the engine stream, exchange on torch's stream, drain it) and says so in `self.mode`."""
 
-    def __init__(self, torch, dist, device, stream_ptr=None):
+    def __init__(self, torch, dist, device, stream_ptr=None, ordered=True):
         self.torch, self.dist, self.device = torch, dist, device
         self.stream = None
-        if stream_ptr is not None and device.type == "cuda":
+        self.mode = "host-synchronised"
+        self.exchanges = 0
+        if ordered and stream_ptr is not None and device.type == "cuda":
             self.stream = torch.cuda.ExternalStream(stream_ptr, device=device)
+            self.mode = "stream-ordered"
 
     def allocate(self, n_send, n_recv):
         t = self.torch
@@ -187,7 +192,7 @@ class TorchTransport:
     def pointer(self, tensor):
         return tensor.data_ptr()
 
-    def exchange(self, send, recv, segs, engine):
+    def _ops(self, send, recv, segs):
         dist = self.dist
         ops = []
         for s in segs:
@@ -197,15 +202,32 @@ class TorchTransport:
             for off, n in s["recv"]:
                 if n:
                     ops.append(dist.P2POp(dist.irecv, recv[off:off + n], s["rank"]))
+        return ops
+
+    def exchange(self, send, recv, segs, engine):
+        ops = self._ops(send, recv, segs)
         if not ops:
             return
         if self.stream is not None:
-            with self.torch.cuda.stream(self.stream):
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
-        else:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+            try:
+                with self.torch.cuda.stream(self.stream):
+                    for r in self.dist.batch_isend_irecv(ops):
+                        r.wait()
+                self.exchanges += 1
+                return
+            except Exception as exc:  # first use only: later failures are real errors
+                if self.exchanges:
+                    raise
+                self.stream = None
+                self.mode = "host-synchronised (stream-ordered exchange failed: %s)" % type(exc).__name__
+                ops = self._ops(send, recv, segs)
+        if self.device.type == "cuda":
+            engine.sync()                       # pack kernel done
+        for r in self.dist.batch_isend_irecv(ops):
+            r.wait()
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)   # data landed before the unpack kernel is enqueued
+        self.exchanges += 1
 
 
 def gather_owned(plan, buf):

@@ -15,7 +15,7 @@ eng.halo_configure([0, 1, 2], [5, 6, 7], [0], [3])
 send = torch.zeros(3 * 6 + 2, device="cuda"); recv = torch.zeros(3 * 6 + 2, device="cuda")
 eng.step(4)
 eng.halo_pack(send.data_ptr())
-with torch.cuda.stream(ext):
+with torch.cuda.stream(ext):  # same form as halo.TorchTransport (stream-ordered)
     ops = [dist.P2POp(dist.isend, send, 0), dist.P2POp(dist.irecv, recv, 0)]
     for r in dist.batch_isend_irecv(ops):
         r.wait()
