@@ -350,3 +350,13 @@ def test_reupload_replaces_everything(sb, oracle):
         ref.step(70)
         assert_same(eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy()), "re-upload %dx%d" % (w, h))
     eng.destroy()
+
+
+@pytest.mark.parametrize("tile,mode", [(3000, OFF), (2500, GRID)])
+def test_tiles_larger_than_the_prefetch_window(sb, oracle, tile, mode):
+    """Tiles above 2 x 512 particles take the tail loops of k_substep_tiled (phase 0, phase 2, grid ranges)."""
+    buf = sb.scenes.lattice_buffers(80, 75, d=30.0, origin=(60.0, 12.0), jitter=1.0, layout=2, velocity=(0.5, -3.0))
+    got, exp, info = run_both(sb, oracle, buf, n=150, mode=mode, path=TILED, bounds=4000.0, tile=tile)
+    assert info["tiles"] in (2, 3)
+    assert_same(got, exp, "tile %d" % tile)
+    assert (got.particles[:, 1] == 10.0).any()
