@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--collisions", choices=["off", "grid"], default="off")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
-    ap.add_argument("--ghost-depth", type=int, default=32,
+    ap.add_argument("--ghost-depth", type=int, default=24,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
     ap.add_argument("--subticks", type=int, default=64)
     ap.add_argument("--mixed-stiffness", action="store_true",

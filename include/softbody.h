@@ -161,6 +161,12 @@ sb_status sb_halo_configure(sb_engine *e, const uint32_t *ghost_particles, uint3
                             const uint32_t *send_particles, uint32_t n_send_particles,
                             const uint32_t *ghost_beams, uint32_t n_ghost_beams,
                             const uint32_t *send_beams, uint32_t n_send_beams);
+/* Optional: where each list entry lives inside the packed buffers, as FLOAT offsets (6 floats per
+ * particle entry, 2 per beam entry).  Default (or NULL): all particles back to back, then all beams.
+ * A caller with several neighbours uses this to make each neighbour's share one contiguous segment
+ * (one send and one receive per neighbour).  Call after sb_halo_configure. */
+sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *send_particle_off, const uint32_t *send_beam_off,
+                             const uint32_t *ghost_particle_off, const uint32_t *ghost_beam_off);
 /* current state of the send lists -> DEVICE buffer of (6*n_send_particles + 2*n_send_beams) floats
  * (particles first), enqueued on the engine's stream. */
 sb_status sb_halo_pack(sb_engine *e, void *device_dst);

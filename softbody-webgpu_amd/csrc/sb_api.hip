@@ -14,6 +14,8 @@
 
 #include "sb_engine.h"
 
+extern "C" sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *);
+
 static thread_local std::string g_create_error;
 
 #define SB_FAIL(e, code, ...)                                   \
@@ -775,6 +777,37 @@ static sb_status sb_halo_configure_impl(sb_engine *e, const uint32_t *ghost_part
     e->n_ghost_b = n_gb;
     e->n_send_b = n_sb;
     e->n_ghost_b_copies = (uint32_t)ghost_copies.size();
+    SB_TRY(dev_alloc(e, &e->d_send_p_off, n_sp));
+    SB_TRY(dev_alloc(e, &e->d_send_b_off, n_sb));
+    SB_TRY(dev_alloc(e, &e->d_ghost_p_off, n_gp));
+    SB_TRY(dev_alloc(e, &e->d_ghost_b_off, n_gb));
+    return sb_halo_set_layout(e, nullptr, nullptr, nullptr, nullptr); // default: particles back to back, then beams
+}
+
+sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *send_p_off, const uint32_t *send_b_off,
+                             const uint32_t *ghost_p_off, const uint32_t *ghost_b_off)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_set_layout before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    auto put = [&](uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t base, uint32_t stride) -> sb_status {
+        if (!n) return SB_OK;
+        std::vector<uint32_t> dflt;
+        if (!src) {
+            dflt.resize(n);
+            for (uint32_t k = 0; k < n; k++) dflt[k] = base + stride * k;
+            src = dflt.data();
+        }
+        for (uint32_t k = 0; k < n; k++)
+            if (src[k] & 1u) SB_FAIL(e, SB_ERR_INVALID, "halo offsets must be even (8-byte aligned records)");
+        SB_HIP(e, hipMemcpy(dst, src, (size_t)n * 4, hipMemcpyHostToDevice));
+        return SB_OK;
+    };
+    SB_TRY(put(e->d_send_p_off, send_p_off, e->n_send_p, 0, 6));
+    SB_TRY(put(e->d_send_b_off, send_b_off, e->n_send_b, 6 * e->n_send_p, 2));
+    SB_TRY(put(e->d_ghost_p_off, ghost_p_off, e->n_ghost_p, 0, 6));
+    SB_TRY(put(e->d_ghost_b_off, ghost_b_off, e->n_ghost_b, 6 * e->n_ghost_p, 2));
     return SB_OK;
 }
 

@@ -66,6 +66,8 @@ struct sb_engine {
     uint32_t *d_send_b = nullptr;      // one copy per sent beam
     uint2 *d_ghost_b = nullptr;        // (copy index, position in the ghost beam list), every copy
     uint32_t n_ghost_b = 0, n_send_b = 0, n_ghost_b_copies = 0;
+    uint32_t *d_send_p_off = nullptr, *d_send_b_off = nullptr;   // float offsets into the packed send buffer
+    uint32_t *d_ghost_p_off = nullptr, *d_ghost_b_off = nullptr; // float offsets into the packed recv buffer
 
     // tiled path
     uint32_t ntiles = 0, tile_cap_own = 0, tile_cap_all = 0;

@@ -510,41 +510,45 @@ __global__ __launch_bounds__(SB_BLOCK) void k_delete(SbBeamArrays b, uint32_t nw
 
 // ---------------------------------------------------------------- halo exchange helpers
 
-// send lists -> packed float buffer: [6 floats per particle][2 floats per beam]
+// send lists -> packed float buffer (6 floats per particle, 2 per beam, at the configured offsets)
 __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(SbParticleArrays c, SbBeamArrays b,
-                                                        const uint32_t *__restrict__ plist, uint32_t np,
-                                                        const uint32_t *__restrict__ blist, uint32_t nb, float *dst)
+                                                        const uint32_t *__restrict__ plist,
+                                                        const uint32_t *__restrict__ poff, uint32_t np,
+                                                        const uint32_t *__restrict__ blist,
+                                                        const uint32_t *__restrict__ boff, uint32_t nb, float *dst)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (k < np) {
         uint32_t i = plist[k];
         float2 p = c.pos[i], v = c.vel[i], a = c.acc[i];
-        float2 *o = (float2 *)(dst + 6 * (size_t)k);
+        float2 *o = (float2 *)(dst + poff[k]);
         o[0] = p;
         o[1] = v;
         o[2] = a;
     } else if (k < np + nb) {
         uint32_t j = k - np, cpy = blist[j];
-        *(float2 *)(dst + 6 * (size_t)np + 2 * (size_t)j) = make_float2(b.target[cpy], b.last[cpy]);
+        *(float2 *)(dst + boff[j]) = make_float2(b.target[cpy], b.last[cpy]);
     }
 }
 
 // packed float buffer -> ghost lists (every device copy of a ghost beam is refreshed)
 __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, SbBeamArrays b,
-                                                          const uint32_t *__restrict__ plist, uint32_t np,
-                                                          const uint2 *__restrict__ blist, uint32_t nbc,
+                                                          const uint32_t *__restrict__ plist,
+                                                          const uint32_t *__restrict__ poff, uint32_t np,
+                                                          const uint2 *__restrict__ blist,
+                                                          const uint32_t *__restrict__ boff, uint32_t nbc,
                                                           const float *__restrict__ src)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (k < np) {
         uint32_t i = plist[k];
-        const float2 *in = (const float2 *)(src + 6 * (size_t)k);
+        const float2 *in = (const float2 *)(src + poff[k]);
         c.pos[i] = in[0];
         c.vel[i] = in[1];
         c.acc[i] = in[2];
     } else if (k < np + nbc) {
         uint2 e = blist[k - np];
-        float2 tl = *(const float2 *)(src + 6 * (size_t)np + 2 * (size_t)e.y);
+        float2 tl = *(const float2 *)(src + boff[e.y]);
         b.target[e.x] = tl.x;
         b.last[e.x] = tl.y;
     }
@@ -612,16 +616,17 @@ void sbk_launch_halo_pack(sb_engine *e, float *dst)
 {
     uint32_t n = e->n_send_p + e->n_send_b;
     if (!n) return;
-    k_halo_pack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p, e->n_send_p,
-                                                              e->d_send_b, e->n_send_b, dst);
+    k_halo_pack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p, e->d_send_p_off,
+                                                              e->n_send_p, e->d_send_b, e->d_send_b_off, e->n_send_b, dst);
 }
 
 void sbk_launch_halo_unpack(sb_engine *e, const float *src)
 {
     uint32_t n = e->n_ghost_p + e->n_ghost_b_copies;
     if (!n) return;
-    k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->n_ghost_p,
-                                                                e->d_ghost_b, e->n_ghost_b_copies, src);
+    k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->d_ghost_p_off,
+                                                                e->n_ghost_p, e->d_ghost_b, e->d_ghost_b_off,
+                                                                e->n_ghost_b_copies, src);
     if (e->d_grid_ctl) (void)hipMemsetAsync(&e->d_grid_ctl->force, 0x01, 4, e->stream); // ghosts jumped: rebin
     // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
     if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);

@@ -89,6 +89,7 @@ def load_library():
     L.sb_get_counts.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.sb_get_info.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
     L.sb_halo_configure.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
+    L.sb_halo_set_layout.argtypes = [vp, vp, vp, vp, vp]
     L.sb_halo_pack.argtypes = [vp, vp]
     L.sb_halo_unpack.argtypes = [vp, vp]
     L.sb_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
@@ -200,6 +201,11 @@ class Engine:
         a = [np.ascontiguousarray(x, dtype="<u4") for x in (ghost_particles, send_particles, ghost_beams, send_beams)]
         self._check(load_library().sb_halo_configure(self._h, _ptr(a[0]), a[0].size, _ptr(a[1]), a[1].size,
                                                      _ptr(a[2]), a[2].size, _ptr(a[3]), a[3].size))
+
+    def halo_set_layout(self, send_particle_off, send_beam_off, ghost_particle_off, ghost_beam_off):
+        a = [np.ascontiguousarray(x, dtype="<u4") for x in (send_particle_off, send_beam_off, ghost_particle_off,
+                                                             ghost_beam_off)]
+        self._check(load_library().sb_halo_set_layout(self._h, *[_ptr(x) for x in a]))
 
     def halo_pack(self, device_ptr):
         self._check(load_library().sb_halo_pack(self._h, ctypes.c_void_p(device_ptr)))

@@ -57,21 +57,23 @@ class HaloPlan:
                 cat([p.ghost_b for p in self.peers]), cat([p.send_b for p in self.peers]))
 
     def segments(self):
-        """Per peer: float offsets/lengths inside the packed send and recv buffers
-        (layout: all particles x6 floats, then all beams x2 floats; peers in order)."""
-        gp, sp, gb, sb_ = self.lists()
-        out = []
-        so_p = ro_p = 0
-        so_b, ro_b = 6 * sp.size, 6 * gp.size
+        """Packed buffer layout with ONE contiguous segment per peer and direction:
+        [peer 0: particles x6 floats, beams x2 floats][peer 1: ...].  Returns (per-peer segments,
+        send floats, recv floats, (send_p_off, send_b_off, ghost_p_off, ghost_b_off)) where the
+        offset arrays follow the concatenated list order of `lists()`."""
+        out, offs = [], [[], [], [], []]
+        so = ro = 0
         for p in self.peers:
-            out.append(dict(rank=p.rank,
-                            send=[(so_p, 6 * p.send_p.size), (so_b, 2 * p.send_b.size)],
-                            recv=[(ro_p, 6 * p.ghost_p.size), (ro_b, 2 * p.ghost_b.size)]))
-            so_p += 6 * p.send_p.size
-            ro_p += 6 * p.ghost_p.size
-            so_b += 2 * p.send_b.size
-            ro_b += 2 * p.ghost_b.size
-        return out, 6 * sp.size + 2 * sb_.size, 6 * gp.size + 2 * gb.size
+            ns, nr = 6 * p.send_p.size + 2 * p.send_b.size, 6 * p.ghost_p.size + 2 * p.ghost_b.size
+            out.append(dict(rank=p.rank, send=[(so, ns)], recv=[(ro, nr)]))
+            offs[0].append(so + 6 * np.arange(p.send_p.size))
+            offs[1].append(so + 6 * p.send_p.size + 2 * np.arange(p.send_b.size))
+            offs[2].append(ro + 6 * np.arange(p.ghost_p.size))
+            offs[3].append(ro + 6 * p.ghost_p.size + 2 * np.arange(p.ghost_b.size))
+            so += ns
+            ro += nr
+        cat = lambda xs: np.concatenate(xs).astype("<u4") if xs else np.zeros(0, "<u4")  # noqa: E731
+        return out, so, ro, tuple(cat(x) for x in offs)
 
 
 def slab_scene(sb, rank, world, W, H, d=30.0, origin=(1000.0, 1000.0), jitter=0.0, depth=8, seed=1,
@@ -143,7 +145,8 @@ class Exchanger:
         self.since = 0
         gp, sp, gb, sb_ = plan.lists()
         engine.halo_configure(gp, sp, gb, sb_)
-        self.segs, n_send, n_recv = plan.segments()
+        self.segs, n_send, n_recv, offsets = plan.segments()
+        engine.halo_set_layout(*offsets)
         self.send, self.recv = transport.allocate(n_send, n_recv)
 
     def exchange(self):

@@ -16,24 +16,32 @@ class OracleRank:
 
     def halo_configure(self, gp, sp, gb, sb_):
         self.gp, self.sp, self.gb, self.sb = [np.asarray(x, dtype=np.int64) for x in (gp, sp, gb, sb_)]
+        self.halo_set_layout(6 * np.arange(self.sp.size), 6 * self.sp.size + 2 * np.arange(self.sb.size),
+                             6 * np.arange(self.gp.size), 6 * self.gp.size + 2 * np.arange(self.gb.size))
+
+    def halo_set_layout(self, sp_off, sb_off, gp_off, gb_off):
+        self.sp_off, self.sb_off, self.gp_off, self.gb_off = [np.asarray(x, dtype=np.int64) for x in
+                                                              (sp_off, sb_off, gp_off, gb_off)]
 
     def _cur(self):
         return self.ref.particles_b if self.ref.final_in_b else self.ref.particles_a
 
     def halo_pack(self, dst):
         dst = np.asarray(dst)
-        n = self.sp.size
-        dst[:6 * n] = self._cur()[self.sp].reshape(-1)
+        if self.sp.size:
+            dst[self.sp_off[:, None] + np.arange(6)] = self._cur()[self.sp]
         b = self.ref.beams
-        dst[6 * n:6 * n + 2 * self.sb.size] = np.stack([b["target_length"][self.sb], b["last_length"][self.sb]], 1).reshape(-1)
+        if self.sb.size:
+            dst[self.sb_off] = b["target_length"][self.sb]
+            dst[self.sb_off + 1] = b["last_length"][self.sb]
 
     def halo_unpack(self, src):
         src = np.asarray(src)
-        n = self.gp.size
-        self._cur()[self.gp] = src[:6 * n].reshape(-1, 6)
-        tl = src[6 * n:6 * n + 2 * self.gb.size].reshape(-1, 2)
-        self.ref.beams["target_length"][self.gb] = tl[:, 0]
-        self.ref.beams["last_length"][self.gb] = tl[:, 1]
+        if self.gp.size:
+            self._cur()[self.gp] = src[self.gp_off[:, None] + np.arange(6)]
+        if self.gb.size:
+            self.ref.beams["target_length"][self.gb] = src[self.gb_off]
+            self.ref.beams["last_length"][self.gb] = src[self.gb_off + 1]
 
     def load(self, buf):
         return self.ref.load_buffers(buf.copy())
