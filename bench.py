@@ -39,9 +39,14 @@ def parse():
     ap.add_argument("--subticks", type=int, default=64)
     ap.add_argument("--mixed-stiffness", action="store_true",
                     help="BASELINE config 5: springs drawn from {1,3,50,500}, use with --subticks 128")
-    ap.add_argument("--exchange", choices=["stream", "sync"], default="stream",
-                    help="N>1: RCCL exchange ordered on the engine stream (default) or host-synchronised")
+    ap.add_argument("--exchange", choices=["peer", "stream", "sync"], default="peer",
+                    help="N>1: ghost refresh by direct stores into the neighbours' IPC-mapped mailboxes (default; "
+                         "falls back to 'stream' if the mappings cannot be set up or fail their check), by RCCL "
+                         "send/recv ordered on the engine stream, or by host-synchronised RCCL")
     ap.add_argument("--grid-skin", type=float, default=0.0, help="spatial-hash skin (0 = engine default)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 on a single-GPU box: every rank uses cuda:0 and the process group is gloo (control "
+                         "plane only), so the multi-rank code path and the peer exchange can be exercised; not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -100,6 +105,52 @@ def committed_traffic(workload, kernel):
     return best
 
 
+def peer_exchanger(halo, eng, plan, buf, dist, torch, ctl):
+    """Direct neighbour exchange (sb_peer_*), agreed on by ALL ranks or by none: every rank sets its
+    mailbox up, maps its neighbours', runs one refresh on the freshly uploaded state (where it must
+    reproduce the ghost zone bit for bit) and the ranks vote.  None = use the RCCL transport."""
+    import numpy as np
+    world = dist.get_world_size()
+
+    def vote(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    ex, why = None, None
+    try:
+        ex = halo.PeerExchanger(eng, plan, timeout_ms=20000)
+    except Exception as exc:  # noqa: BLE001 -- any failure means "use RCCL"
+        why = "mailbox: %r" % (exc,)
+    cards = [None] * world
+    dist.all_gather_object(cards, ex.card if ex is not None else None)
+    if ex is not None and all(c is not None for c in cards):
+        try:
+            ex.connect(cards)
+        except Exception as exc:  # noqa: BLE001
+            why = "connect: %r" % (exc,)
+    ok = vote(ex is not None and ex.connected)
+    if ok:
+        try:
+            ex.exchange()
+            eng.sync()
+            out = eng.load_buffers(buf.copy())
+            gp, _, gb, _ = plan.lists()
+            same = np.array_equal(out.particles[gp].view("u4"), buf.particles[gp].view("u4"))
+            for f in ("target_length", "last_length"):
+                same = same and np.array_equal(out.beams[f][gb].view("u4"), buf.beams[f][gb].view("u4"))
+            if not same:
+                why = "check: the refreshed ghost zone differs from the owners' state"
+            ok = same
+        except Exception as exc:  # noqa: BLE001
+            why, ok = "check: %r" % (exc,), False
+        ok = vote(ok)
+    if why:
+        print("[bench rank %d] direct peer exchange unavailable (%s)" % (dist.get_rank(), why), file=sys.stderr, flush=True)
+    dist.barrier()
+    return ex if ok else None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -114,11 +165,18 @@ def main():
     sb = ge.load_package()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if a.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
+    ctl = "cpu" if a.rehearse_one_gpu else "cuda"      # where the few control-plane tensors live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+            a.exchange = "peer"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from importlib import import_module
     halo = import_module("softbody_webgpu_amd.halo") if world > 1 else None
@@ -145,12 +203,22 @@ def main():
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
                     path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin)
     eng.write_buffers(buf)
+    exchange_mode = None
     if plan is None:
         stepper = eng.step
     else:
-        transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream(),
-                                        ordered=a.exchange == "stream")
-        stepper = halo.Exchanger(eng, plan, transport).step
+        ex = peer_exchanger(halo, eng, plan, buf, dist, torch, ctl) if a.exchange == "peer" else None
+        if ex is not None:
+            exchange_mode = "direct stores into the neighbours' IPC-mapped mailboxes, flag handshake on the engine stream"
+        else:
+            if a.rehearse_one_gpu:
+                sys.exit("--rehearse-one-gpu: the peer exchange could not be set up and RCCL cannot share one GPU")
+            if a.exchange == "peer":
+                eng.write_buffers(buf)          # back to the uploaded state, mailboxes released
+            transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream(),
+                                            ordered=a.exchange != "sync")
+            ex = halo.Exchanger(eng, plan, transport)
+        stepper = ex.step
 
     def barrier():
         eng.sync()                 # the engine runs on its own HIP stream
@@ -170,10 +238,10 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-        cnt = torch.tensor([P_local], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([P_local], dtype=torch.float64, device=ctl)
         dist.all_reduce(cnt)
         P_total = int(cnt.item())
     else:
@@ -210,14 +278,15 @@ def main():
             "metric": "particle-steps/sec", "value": P_total * a.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not a.rehearse_one_gpu else "synthetic; REHEARSAL: all ranks share one GPU, not a measurement",
             "config": {"workload": workload,
                        "particles_total": P_total, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
                        "tiles": eng.info("tiles"), "grid_builds": eng.info("grid_builds") if mode == 2 else None,
                        "parallelism": "single GPU" if world == 1 else
-                       "%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, RCCL neighbour "
-                       "send/recv of ghost p,v,a + beam target/last every %d substeps (%s)"
-                       % (world, W, a.ghost_depth, a.ghost_depth, transport.mode)},
+                       "%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, ghost p,v,a + "
+                       "beam target/last refreshed every %d substeps (%s)"
+                       % (world, W, a.ghost_depth, a.ghost_depth,
+                          exchange_mode or "RCCL neighbour send/recv, " + transport.mode)},
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -173,6 +173,29 @@ sb_status sb_halo_pack(sb_engine *e, void *device_dst);
 /* DEVICE buffer of (6*n_ghost_particles + 2*n_ghost_beams) floats -> current state of the ghost
  * lists, enqueued on the engine's stream. */
 sb_status sb_halo_unpack(sb_engine *e, const void *device_src);
+/* ---- direct neighbour exchange over peer mappings (xGMI stores into the neighbour's mailbox) ----
+ * The alternative to moving the packed buffers with a collective library: every exchange is three
+ * launches on the engine's own stream (pack straight into the neighbours' mailboxes, signal + wait,
+ * unpack), no host synchronisation.  A mailbox is fine-grained device memory: 64 u32 sequence flags
+ * (256 B), then two receive buffers (alternating by exchange parity) of the packed receive layout,
+ * each rounded up to 256 B.  Order of calls: sb_halo_configure [+ sb_halo_set_layout] ->
+ * sb_peer_mailbox on every rank -> trade the 64-byte handles -> sb_peer_map for each neighbour in
+ * another process (a neighbour engine in the same process passes its local pointer directly) ->
+ * sb_peer_connect -> sb_peer_exchange whenever the ghost zone must be refreshed.  Every rank must
+ * call sb_peer_exchange the same number of times.  A neighbour that does not show up within
+ * `timeout_ms` makes the wait give up (no hung wave): the next sb_sync reports SB_ERR_HIP. */
+#define SB_MAX_PEERS 8
+sb_status sb_peer_mailbox(sb_engine *e, void **local_mailbox, void *ipc_handle_64_bytes, uint64_t *mailbox_bytes);
+sb_status sb_peer_map(sb_engine *e, const void *ipc_handle_64_bytes, void **mapped_mailbox);
+/* per neighbour j: its mailbox, the float count of ITS packed receive layout, my send segment
+ * [send_begin, send_begin+send_len) (floats, in my packed send layout), where that segment starts in
+ * its receive layout (floats), and which flag slot of its mailbox is mine (= my position in its
+ * neighbour order).  My own flag slot for neighbour j is j. */
+sb_status sb_peer_connect(sb_engine *e, uint32_t n_peers, void *const *mailboxes, const uint32_t *peer_recv_floats,
+                          const uint32_t *send_begin, const uint32_t *send_len, const uint32_t *dst_begin,
+                          const uint32_t *their_slot, uint32_t timeout_ms);
+sb_status sb_peer_exchange(sb_engine *e);
+
 /* the engine's hipStream_t, so a caller can order its own work (RCCL send/recv) after it. */
 sb_status sb_get_stream(sb_engine *e, void **hip_stream);
 

@@ -60,6 +60,11 @@ static void free_scene(sb_engine *e)
     e->device_bytes = 0;
     e->loaded = false;
     e->n_ghost_p = e->n_send_p = e->n_ghost_b = e->n_send_b = e->n_ghost_b_copies = 0;
+    for (void *p : e->mapped) (void)hipIpcCloseMemHandle(p);
+    e->mapped.clear();
+    e->mailbox = nullptr; // was in allocs
+    e->n_peers = e->peer_seq = e->send_floats = e->recv_floats = 0;
+    if (e->peer_err) *e->peer_err = 0;
 }
 
 static inline uint32_t beam_stride(const sb_engine *e)
@@ -165,6 +170,7 @@ sb_status sb_destroy(sb_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     free_scene(e);
+    if (e->peer_err) (void)hipHostFree(e->peer_err);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -556,6 +562,11 @@ sb_status sb_sync(sb_engine *e)
     if (!e) return SB_ERR_INVALID;
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
+    if (e->peer_err && *e->peer_err) {
+        uint32_t who = *e->peer_err;
+        *e->peer_err = 0;
+        SB_FAIL(e, SB_ERR_HIP, "peer exchange: neighbour(s) 0x%x did not signal within %u ms", who, e->peer_timeout_ms);
+    }
     return SB_OK;
 }
 
@@ -791,6 +802,7 @@ sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *send_p_off, const uin
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_set_layout before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
+    uint32_t extent = 0;
     auto put = [&](uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t base, uint32_t stride) -> sb_status {
         if (!n) return SB_OK;
         std::vector<uint32_t> dflt;
@@ -801,13 +813,113 @@ sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *send_p_off, const uin
         }
         for (uint32_t k = 0; k < n; k++)
             if (src[k] & 1u) SB_FAIL(e, SB_ERR_INVALID, "halo offsets must be even (8-byte aligned records)");
+        for (uint32_t k = 0; k < n; k++) extent = std::max(extent, src[k] + stride);
         SB_HIP(e, hipMemcpy(dst, src, (size_t)n * 4, hipMemcpyHostToDevice));
         return SB_OK;
     };
+    if (e->mailbox) SB_FAIL(e, SB_ERR_STATE, "sb_halo_set_layout after sb_peer_mailbox");
     SB_TRY(put(e->d_send_p_off, send_p_off, e->n_send_p, 0, 6));
     SB_TRY(put(e->d_send_b_off, send_b_off, e->n_send_b, 6 * e->n_send_p, 2));
+    e->send_floats = extent;
+    extent = 0;
     SB_TRY(put(e->d_ghost_p_off, ghost_p_off, e->n_ghost_p, 0, 6));
     SB_TRY(put(e->d_ghost_b_off, ghost_b_off, e->n_ghost_b, 6 * e->n_ghost_p, 2));
+    e->recv_floats = extent;
+    return SB_OK;
+}
+
+// ---- direct peer exchange -------------------------------------------------------------------
+static inline size_t mailbox_stride(uint32_t recv_floats) { return ((size_t)recv_floats * 4 + 255) & ~(size_t)255; }
+static const size_t kMailboxFlagsBytes = 256;
+
+sb_status sb_peer_mailbox(sb_engine *e, void **local_mailbox, void *ipc_handle, uint64_t *mailbox_bytes)
+{
+    if (!e || !local_mailbox) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_peer_mailbox before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    if (!e->mailbox) {
+        size_t bytes = kMailboxFlagsBytes + 2 * mailbox_stride(e->recv_floats);
+        void *q = nullptr;
+        // fine-grained: stores arriving over xGMI and the flag polling stay coherent without a kernel boundary
+        SB_HIP(e, hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained));
+        e->allocs.push_back(q);
+        e->device_bytes += bytes;
+        SB_HIP(e, hipMemset(q, 0, bytes));
+        SB_HIP(e, hipDeviceSynchronize());
+        e->mailbox = q;
+        if (!e->peer_err) {
+            SB_HIP(e, hipHostMalloc((void **)&e->peer_err, 64, hipHostMallocMapped));
+            *e->peer_err = 0;
+        }
+    }
+    *local_mailbox = e->mailbox;
+    if (mailbox_bytes) *mailbox_bytes = kMailboxFlagsBytes + 2 * mailbox_stride(e->recv_floats);
+    if (ipc_handle) {
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+        hipIpcMemHandle_t h;
+        SB_HIP(e, hipIpcGetMemHandle(&h, e->mailbox));
+        memcpy(ipc_handle, &h, sizeof h);
+    }
+    return SB_OK;
+}
+
+sb_status sb_peer_map(sb_engine *e, const void *ipc_handle, void **mapped_mailbox)
+{
+    if (!e || !ipc_handle || !mapped_mailbox) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_peer_map before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle, sizeof h);
+    void *q = nullptr;
+    SB_HIP(e, hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+    e->mapped.push_back(q);
+    *mapped_mailbox = q;
+    return SB_OK;
+}
+
+sb_status sb_peer_connect(sb_engine *e, uint32_t n_peers, void *const *mailboxes, const uint32_t *peer_recv_floats,
+                          const uint32_t *send_begin, const uint32_t *send_len, const uint32_t *dst_begin,
+                          const uint32_t *their_slot, uint32_t timeout_ms)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->mailbox) SB_FAIL(e, SB_ERR_STATE, "sb_peer_connect before sb_peer_mailbox");
+    if (n_peers > SB_MAX_PEERS) SB_FAIL(e, SB_ERR_INVALID, "at most %d neighbours", SB_MAX_PEERS);
+    if (n_peers && (!mailboxes || !peer_recv_floats || !send_begin || !send_len || !dst_begin || !their_slot))
+        return SB_ERR_INVALID;
+    for (uint32_t j = 0; j < n_peers; j++) {
+        if (!mailboxes[j]) SB_FAIL(e, SB_ERR_INVALID, "neighbour %u has no mailbox", j);
+        if ((uint64_t)send_begin[j] + send_len[j] > e->send_floats)
+            SB_FAIL(e, SB_ERR_INVALID, "send segment of neighbour %u exceeds the packed send layout", j);
+        if ((uint64_t)dst_begin[j] + send_len[j] > peer_recv_floats[j])
+            SB_FAIL(e, SB_ERR_INVALID, "send segment of neighbour %u does not fit its receive layout", j);
+        if (their_slot[j] >= 64 || ((send_begin[j] | dst_begin[j]) & 1u))
+            SB_FAIL(e, SB_ERR_INVALID, "neighbour %u: bad flag slot or odd segment offset", j);
+        for (uint32_t i = 0; i < j; i++)
+            if (send_begin[j] < send_begin[i] + send_len[i] && send_begin[i] < send_begin[j] + send_len[j])
+                SB_FAIL(e, SB_ERR_INVALID, "send segments of neighbours %u and %u overlap", i, j);
+    }
+    e->n_peers = n_peers;
+    for (uint32_t j = 0; j < n_peers; j++) {
+        e->peer_box[j] = mailboxes[j];
+        e->peer_stride[j] = (uint32_t)mailbox_stride(peer_recv_floats[j]);
+        e->peer_begin[j] = send_begin[j];
+        e->peer_len[j] = send_len[j];
+        e->peer_dst[j] = dst_begin[j];
+        e->peer_slot[j] = their_slot[j];
+    }
+    e->peer_timeout_ms = timeout_ms ? timeout_ms : 10000;
+    e->peer_seq = 0;
+    return SB_OK;
+}
+
+sb_status sb_peer_exchange(sb_engine *e)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded || !e->mailbox) SB_FAIL(e, SB_ERR_STATE, "sb_peer_exchange before sb_peer_connect");
+    if (!e->n_peers) return SB_OK;
+    SB_HIP(e, hipSetDevice(e->device));
+    sbk_launch_peer_exchange(e);
+    SB_HIP(e, hipGetLastError());
     return SB_OK;
 }
 

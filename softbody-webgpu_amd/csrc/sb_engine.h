@@ -68,6 +68,14 @@ struct sb_engine {
     uint32_t n_ghost_b = 0, n_send_b = 0, n_ghost_b_copies = 0;
     uint32_t *d_send_p_off = nullptr, *d_send_b_off = nullptr;   // float offsets into the packed send buffer
     uint32_t *d_ghost_p_off = nullptr, *d_ghost_b_off = nullptr; // float offsets into the packed recv buffer
+    uint32_t send_floats = 0, recv_floats = 0;                   // extents of the two packed layouts
+    // direct peer exchange (sb_peer_*): own mailbox, neighbours' mailboxes, per-neighbour routing
+    void *mailbox = nullptr;
+    std::vector<void *> mapped;        // opened IPC mappings (closed with the scene)
+    uint32_t n_peers = 0, peer_seq = 0, peer_timeout_ms = 0;
+    void *peer_box[8] = {};
+    uint32_t peer_stride[8] = {}, peer_begin[8] = {}, peer_len[8] = {}, peer_dst[8] = {}, peer_slot[8] = {};
+    uint32_t *peer_err = nullptr;      // pinned host word the wait kernel sets when it gives up
 
     // tiled path
     uint32_t ntiles = 0, tile_cap_own = 0, tile_cap_all = 0;
@@ -107,3 +115,4 @@ void sbk_launch_substep(sb_engine *e, bool write_aux);
 void sbk_launch_delete(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float *src);
+void sbk_launch_peer_exchange(sb_engine *e);

@@ -554,6 +554,77 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, Sb
     }
 }
 
+// ---------------------------------------------------------------- direct peer exchange
+#define SB_MAILBOX_FLAGS_BYTES 256
+
+struct SbPeerRoute {
+    uint32_t n;
+    uint32_t begin[SB_MAX_PEERS], end[SB_MAX_PEERS]; // my packed send layout, floats
+    float *dst[SB_MAX_PEERS];                        // where begin[j] lands in neighbour j's current receive buffer
+};
+
+__device__ __forceinline__ float *sb_peer_route(const SbPeerRoute &r, uint32_t off)
+{
+    float *o = nullptr;
+#pragma unroll
+    for (uint32_t j = 0; j < SB_MAX_PEERS; j++)
+        if (j < r.n && off >= r.begin[j] && off < r.end[j]) o = r.dst[j] + (off - r.begin[j]);
+    return o;
+}
+
+// k_halo_pack with the destination resolved per record: the stores go over xGMI into the neighbours'
+// fine-grained mailboxes; they are complete (acknowledged) when the kernel retires.
+__global__ __launch_bounds__(SB_BLOCK) void k_halo_pack_peer(SbParticleArrays c, SbBeamArrays b,
+                                                             const uint32_t *__restrict__ plist,
+                                                             const uint32_t *__restrict__ poff, uint32_t np,
+                                                             const uint32_t *__restrict__ blist,
+                                                             const uint32_t *__restrict__ boff, uint32_t nb,
+                                                             SbPeerRoute route)
+{
+    uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (k < np) {
+        uint32_t i = plist[k];
+        float2 p = c.pos[i], v = c.vel[i], a = c.acc[i];
+        float2 *o = (float2 *)sb_peer_route(route, poff[k]);
+        if (o) {
+            o[0] = p;
+            o[1] = v;
+            o[2] = a;
+        }
+    } else if (k < np + nb) {
+        uint32_t j = k - np, cpy = blist[j];
+        float2 *o = (float2 *)sb_peer_route(route, boff[j]);
+        if (o) *o = make_float2(b.target[cpy], b.last[cpy]);
+    }
+}
+
+struct SbPeerSignal {
+    uint32_t n, seq;
+    uint32_t *remote[SB_MAX_PEERS]; // my flag in each neighbour's mailbox
+    uint32_t *local;                // my mailbox's flags: slot j is written by neighbour j
+    uint64_t limit_ticks;           // wall_clock64 ticks (100 MHz) before the wait gives up
+    uint32_t *err;                  // pinned host word
+};
+
+// One lane per neighbour: publish "my data for exchange `seq` is in your mailbox", then wait until the
+// neighbour has said the same.  Runs as its own launch between pack and unpack, so the data stores are
+// released before the flag and the unpack kernel starts (and acquires) after the flag was seen.  The
+// wait is bounded: a neighbour that never arrives sets *err instead of leaving a wave spinning.
+__global__ __launch_bounds__(64) void k_peer_signal_wait(SbPeerSignal s)
+{
+    uint32_t j = threadIdx.x;
+    if (j >= s.n) return;
+    __hip_atomic_store(s.remote[j], s.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint64_t t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(&s.local[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - s.seq) < 0) {
+        if (wall_clock64() - t0 > s.limit_ticks) {
+            __hip_atomic_fetch_or(s.err, 1u << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // ---------------------------------------------------------------- launchers
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -631,3 +702,37 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
     // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
     if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);
 }
+
+static inline size_t sb_mailbox_stride(uint32_t recv_floats)
+{
+    return ((size_t)recv_floats * 4 + 255) & ~(size_t)255;
+}
+
+void sbk_launch_peer_exchange(sb_engine *e)
+{
+    const uint32_t seq = ++e->peer_seq, par = seq & 1u;
+    SbPeerRoute route{};
+    SbPeerSignal sig{};
+    route.n = sig.n = e->n_peers;
+    sig.seq = seq;
+    for (uint32_t j = 0; j < e->n_peers; j++) {
+        char *box = (char *)e->peer_box[j];
+        route.begin[j] = e->peer_begin[j];
+        route.end[j] = e->peer_begin[j] + e->peer_len[j];
+        route.dst[j] = (float *)(box + SB_MAILBOX_FLAGS_BYTES + (size_t)par * e->peer_stride[j]) + e->peer_dst[j];
+        sig.remote[j] = (uint32_t *)box + e->peer_slot[j];
+    }
+    sig.local = (uint32_t *)e->mailbox;
+    sig.limit_ticks = (uint64_t)e->peer_timeout_ms * 100000ull;
+    sig.err = e->peer_err;
+    uint32_t n = e->n_send_p + e->n_send_b;
+    if (n)
+        k_halo_pack_peer<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p,
+                                                                       e->d_send_p_off, e->n_send_p, e->d_send_b,
+                                                                       e->d_send_b_off, e->n_send_b, route);
+    k_peer_signal_wait<<<1, 64, 0, e->stream>>>(sig);
+    const float *src = (const float *)((char *)e->mailbox + SB_MAILBOX_FLAGS_BYTES +
+                                       (size_t)par * sb_mailbox_stride(e->recv_floats));
+    sbk_launch_halo_unpack(e, src);
+}
+

@@ -91,6 +91,10 @@ def load_library():
     L.sb_halo_configure.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
     L.sb_halo_set_layout.argtypes = [vp, vp, vp, vp, vp]
     L.sb_halo_pack.argtypes = [vp, vp]
+    L.sb_peer_mailbox.argtypes = [vp, ctypes.POINTER(vp), vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.sb_peer_map.argtypes = [vp, vp, ctypes.POINTER(vp)]
+    L.sb_peer_connect.argtypes = [vp, u32, ctypes.POINTER(vp), vp, vp, vp, vp, vp, u32]
+    L.sb_peer_exchange.argtypes = [vp]
     L.sb_halo_unpack.argtypes = [vp, vp]
     L.sb_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.sb_last_error.argtypes = [vp]
@@ -206,6 +210,27 @@ class Engine:
         a = [np.ascontiguousarray(x, dtype="<u4") for x in (send_particle_off, send_beam_off, ghost_particle_off,
                                                              ghost_beam_off)]
         self._check(load_library().sb_halo_set_layout(self._h, *[_ptr(x) for x in a]))
+
+    def peer_mailbox(self):
+        """(local device pointer, 64-byte IPC handle, bytes) of this engine's mailbox (allocated on first call)."""
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+        handle = ctypes.create_string_buffer(64)
+        self._check(load_library().sb_peer_mailbox(self._h, ctypes.byref(ptr), handle, ctypes.byref(nbytes)))
+        return ptr.value, handle.raw, nbytes.value
+
+    def peer_map(self, handle):
+        ptr = ctypes.c_void_p()
+        self._check(load_library().sb_peer_map(self._h, ctypes.c_char_p(bytes(handle)), ctypes.byref(ptr)))
+        return ptr.value
+
+    def peer_connect(self, mailboxes, peer_recv_floats, send_begin, send_len, dst_begin, their_slot, timeout_ms=0):
+        n = len(mailboxes)
+        boxes = (ctypes.c_void_p * max(n, 1))(*mailboxes)
+        a = [np.ascontiguousarray(x, dtype="<u4") for x in (peer_recv_floats, send_begin, send_len, dst_begin, their_slot)]
+        self._check(load_library().sb_peer_connect(self._h, n, boxes, *[_ptr(x) for x in a], int(timeout_ms)))
+
+    def peer_exchange(self):
+        self._check(load_library().sb_peer_exchange(self._h))
 
     def halo_pack(self, device_ptr):
         self._check(load_library().sb_halo_pack(self._h, ctypes.c_void_p(device_ptr)))

@@ -171,6 +171,56 @@ class Exchanger:
                 self.since = 0
 
 
+class PeerExchanger(Exchanger):
+    """Exchanger whose refresh is sb_peer_exchange: the pack kernel stores straight into the neighbours'
+    mailboxes (IPC-mapped device memory, over xGMI between GPUs), a one-wave kernel trades sequence
+    flags, the unpack kernel reads this rank's own mailbox.  Three launches on the engine stream, no
+    collective library and no host synchronisation per exchange.
+
+    Two-phase setup because every rank's mailbox must exist before anyone connects:
+        ex = PeerExchanger(engine, plan);  cards = all_gather(ex.card);  ex.connect(cards)
+    `cards` is indexable by rank."""
+
+    def __init__(self, engine, plan, timeout_ms=10000):
+        self.engine, self.plan, self.transport = engine, plan, None
+        self.since = 0
+        self.timeout_ms = timeout_ms
+        gp, sp, gb, sb_ = plan.lists()
+        engine.halo_configure(gp, sp, gb, sb_)
+        self.segs, n_send, n_recv, offsets = plan.segments()
+        engine.halo_set_layout(*offsets)
+        ptr, handle, _ = engine.peer_mailbox()
+        import os
+        self.card = dict(rank=plan.rank, pid=os.getpid(), pointer=ptr, handle=handle, recv_floats=n_recv,
+                         recv=[(s["rank"],) + s["recv"][0] for s in self.segs])
+        self.connected = False
+
+    def connect(self, cards):
+        boxes, rfl, sbeg, slen, dbeg, slot = [], [], [], [], [], []
+        for s in self.segs:
+            them = cards[s["rank"]]
+            mine = [k for k, (r, _, _) in enumerate(them["recv"]) if r == self.plan.rank]
+            if len(mine) != 1:
+                raise ValueError("rank %d does not list rank %d as a neighbour" % (s["rank"], self.plan.rank))
+            _, ro, rn = them["recv"][mine[0]]
+            (so, sn), = s["send"]
+            if sn != rn:
+                raise ValueError("rank %d sends %d floats to rank %d, which expects %d" % (self.plan.rank, sn, s["rank"], rn))
+            same_process = them["pid"] == self.card["pid"]
+            boxes.append(them["pointer"] if same_process else self.engine.peer_map(them["handle"]))
+            rfl.append(them["recv_floats"])
+            sbeg.append(so)
+            slen.append(sn)
+            dbeg.append(ro)
+            slot.append(mine[0])
+        self.engine.peer_connect(boxes, rfl, sbeg, slen, dbeg, slot, self.timeout_ms)
+        self.connected = True
+
+    def exchange(self):
+        if self.plan.peers:
+            self.engine.peer_exchange()
+
+
 class TorchTransport:
     """Neighbour exchange over torch.distributed.  On GPU (`ordered=True`) the P2P ops are issued while
     the engine's own HIP stream is torch's current stream, so RCCL waits for the pack kernel and the

@@ -43,6 +43,41 @@ class OracleRank:
             self.ref.beams["target_length"][self.gb] = src[self.gb_off]
             self.ref.beams["last_length"][self.gb] = src[self.gb_off + 1]
 
+    # ---- sb_peer_* double: mailboxes are numpy arrays in a registry keyed by a fake pointer; the exchange is
+    # split in two (post / collect) because simulated ranks run one after another, not concurrently
+    MAILBOXES = {}
+
+    def peer_mailbox(self):
+        n = int(max((self.gp_off + 6).max() if self.gp.size else 0, (self.gb_off + 2).max() if self.gb.size else 0))
+        self.box = dict(flags=np.zeros(64, "u4"), bufs=[np.zeros(n, "f4"), np.zeros(n, "f4")])
+        ptr = 0x1000 + len(OracleRank.MAILBOXES)
+        OracleRank.MAILBOXES[ptr] = self.box
+        return ptr, b"\0" * 64, 256 + 8 * n
+
+    def peer_map(self, handle):
+        raise AssertionError("simulated ranks share one process: connect() must use the local pointer")
+
+    def peer_connect(self, boxes, recv_floats, send_begin, send_len, dst_begin, their_slot, timeout_ms=0):
+        self.peers = [dict(box=OracleRank.MAILBOXES[b], begin=int(sb), len=int(sl), dst=int(db), slot=int(ts))
+                      for b, sb, sl, db, ts in zip(boxes, send_begin, send_len, dst_begin, their_slot)]
+        for p, n in zip(self.peers, recv_floats):
+            assert p["box"]["bufs"][0].size == n
+        self.seq = 0
+
+    def peer_post(self):
+        self.seq += 1
+        n = int(max((self.sp_off + 6).max() if self.sp.size else 0, (self.sb_off + 2).max() if self.sb.size else 0))
+        packed = np.zeros(n, "f4")
+        self.halo_pack(packed)
+        for p in self.peers:
+            p["box"]["bufs"][self.seq & 1][p["dst"]:p["dst"] + p["len"]] = packed[p["begin"]:p["begin"] + p["len"]]
+            p["box"]["flags"][p["slot"]] = self.seq
+
+    def peer_collect(self):
+        for j in range(len(self.peers)):
+            assert self.box["flags"][j] == self.seq, "neighbour %d has not posted exchange %d" % (j, self.seq)
+        self.halo_unpack(self.box["bufs"][self.seq & 1])
+
     def load(self, buf):
         return self.ref.load_buffers(buf.copy())
 
@@ -118,4 +153,24 @@ def step_all(exchangers, bus, n, copy, sync=lambda: None):
             sync()
             for ex in exchangers:
                 ex.engine.halo_unpack(ex.transport.pointer(ex.recv))
+            since = 0
+
+
+def step_all_peer(exchangers, n):
+    """step_all for PeerExchangers over OracleRank doubles (post everywhere, then collect everywhere)."""
+    k = exchangers[0].plan.depth
+    since = 0
+    while n > 0:
+        m = min(n, k - since) if k > 0 else n
+        for ex in exchangers:
+            ex.engine.step(m)
+        since += m
+        n -= m
+        if k > 0 and since == k:
+            for ex in exchangers:
+                if ex.plan.peers:
+                    ex.engine.peer_post()
+            for ex in exchangers:
+                if ex.plan.peers:
+                    ex.engine.peer_collect()
             since = 0

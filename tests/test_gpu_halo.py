@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
@@ -62,3 +63,89 @@ def test_simulated_gpu_ranks_equal_single_engine(sb, world, depth, path):
     for k, rec in zip(gplan.global_beam_key, want.beams):
         assert beams[int(k)] == rec.tobytes()[8:]
     assert (want.particles[:, 1] == 10.0).any()
+
+
+@pytest.mark.parametrize("world,depth", [(2, 4), (3, 8)])
+def test_peer_exchange_in_process_equals_single_engine(sb, world, depth):
+    """sb_peer_* between engines of one process (each on its own stream, mailboxes passed by pointer):
+    pack-into-neighbour, flag handshake and unpack, all device-side; merged result bit-identical."""
+    halo = sb.halo
+    W, H, steps = 40, 48, 100
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.5)
+
+    def engine_for(buf):
+        e = sb.Engine(bounds_size=8000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                      collision_mode=0, path=2, tile_particles=256)
+        e.write_buffers(buf)
+        return e
+
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    ref = engine_for(gbuf)
+    ref.step(steps)
+    want = ref.load_buffers(gbuf.copy())
+    ref.destroy()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng = engine_for(buf)
+        exs.append(halo.PeerExchanger(eng, plan, timeout_ms=3000))
+        made.append((buf, plan, eng))
+    cards = [ex.card for ex in exs]
+    for ex in exs:
+        ex.connect(cards)
+    # one exchange period at a time per rank: every wait kernel's counterpart is already enqueued on
+    # another stream before the host moves on, and nothing here blocks the host
+    done = 0
+    while done < steps:
+        m = min(depth, steps - done)
+        for ex in exs:
+            ex.step(m)
+        done += m
+    for _, _, eng in made:
+        eng.sync()          # raises if a wait gave up
+    parts = np.zeros_like(want.particles)
+    beams = {}
+    for buf, plan, eng in made:
+        out = eng.load_buffers(buf.copy())
+        gid, prt, bkey, brec = halo.gather_owned(plan, out)
+        parts[gid] = prt
+        for k, rec in zip(bkey, brec):
+            beams[int(k)] = rec.tobytes()[8:]
+        eng.destroy()
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)] == rec.tobytes()[8:]
+
+
+def test_peer_wait_gives_up_instead_of_hanging(sb):
+    """A neighbour that never posts: the bounded wait ends, sb_sync reports it, the engine stays usable."""
+    halo = sb.halo
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0)
+    exs = []
+    for r in range(2):
+        buf, plan = halo.slab_scene(sb, r, 2, 8, 8, depth=2, **kw)
+        e = sb.Engine(bounds_size=8000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                      collision_mode=0)
+        e.write_buffers(buf)
+        exs.append(halo.PeerExchanger(e, plan, timeout_ms=200))
+    for ex in exs:
+        ex.connect([x.card for x in exs])
+    exs[0].engine.peer_exchange()       # rank 1 never calls it
+    with pytest.raises(sb.EngineError, match="did not signal"):
+        exs[0].engine.sync()
+    exs[0].engine.step(2)
+    exs[0].engine.sync()
+    for ex in exs:
+        ex.engine.destroy()
+
+
+def test_two_processes_peer_exchange(sb):
+    """IPC-mapped mailboxes between two OS processes on this GPU (tests/halo_peer_worker.py)."""
+    import subprocess
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "halo_peer_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "HALO_PEER_OK" in p.stdout
+

@@ -86,6 +86,35 @@ def test_simulated_ranks_equal_single_run(sb, oracle, world, depth, steps):
     assert (want.particles[:, 1] == 10.0).any()  # the lattice reached the floor
 
 
+@pytest.mark.parametrize("world,depth", [(2, 3), (4, 2)])
+def test_peer_exchanger_routing_equals_single_engine(sb, oracle, world, depth):
+    """PeerExchanger's wiring (whose mailbox, which flag slot, which destination offset) on oracle-backed
+    doubles of sb_peer_*: merged result is bit-identical to the unsharded run."""
+    from halo_oracle import OracleRank, step_all_peer
+    halo = sb.halo
+    W, H, steps = 6, 7, 40
+    kw = dict(d=25.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.5)
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    ref = OracleRank(oracle, gbuf, 1000.0)
+    ref.step(steps)
+    want = ref.load(gbuf)
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng = OracleRank(oracle, buf, 1000.0)
+        exs.append(halo.PeerExchanger(eng, plan))
+        made.append((buf, plan, eng))
+    cards = [ex.card for ex in exs]
+    for ex in exs:
+        ex.connect(cards)
+    assert [p["slot"] for p in exs[1].engine.peers] == ([0] if world == 2 else [0, 0])
+    step_all_peer(exs, steps)
+    parts, beams = merged_state([(plan, eng.load(buf)) for buf, plan, eng in made], W * world * H, None)
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)].tobytes()[8:] == rec.tobytes()[8:], "beam %d" % k
+
+
 def test_without_refresh_ghost_zone_goes_stale(sb, oracle):
     """Negative control: skipping the exchange must change the owned result (the test above is
     sensitive to the halo logic)."""
