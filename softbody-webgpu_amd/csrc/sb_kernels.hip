@@ -581,18 +581,16 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack_peer(SbParticleArrays c,
                                                              const uint32_t *__restrict__ boff, uint32_t nb,
                                                              SbPeerRoute route)
 {
-    uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (k < np) {
-        uint32_t i = plist[k];
-        float2 p = c.pos[i], v = c.vel[i], a = c.acc[i];
+    // one float2 per lane, consecutive lanes -> consecutive 8-byte words of the mailbox: the stores that
+    // cross xGMI are fully coalesced (a lane per 24-byte record would leave every 64-byte packet a third full)
+    uint32_t t = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (t < 3 * np) {
+        uint32_t k = t / 3, part = t - 3 * k, i = plist[k];
+        const float2 *src = part == 0 ? c.pos : part == 1 ? c.vel : c.acc;
         float2 *o = (float2 *)sb_peer_route(route, poff[k]);
-        if (o) {
-            o[0] = p;
-            o[1] = v;
-            o[2] = a;
-        }
-    } else if (k < np + nb) {
-        uint32_t j = k - np, cpy = blist[j];
+        if (o) o[part] = src[i];
+    } else if (t < 3 * np + nb) {
+        uint32_t j = t - 3 * np, cpy = blist[j];
         float2 *o = (float2 *)sb_peer_route(route, boff[j]);
         if (o) *o = make_float2(b.target[cpy], b.last[cpy]);
     }
@@ -725,7 +723,7 @@ void sbk_launch_peer_exchange(sb_engine *e)
     sig.local = (uint32_t *)e->mailbox;
     sig.limit_ticks = (uint64_t)e->peer_timeout_ms * 100000ull;
     sig.err = e->peer_err;
-    uint32_t n = e->n_send_p + e->n_send_b;
+    uint32_t n = 3 * e->n_send_p + e->n_send_b;
     if (n)
         k_halo_pack_peer<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p,
                                                                        e->d_send_p_off, e->n_send_p, e->d_send_b,
