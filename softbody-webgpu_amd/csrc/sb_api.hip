@@ -64,7 +64,7 @@ static void free_scene(sb_engine *e)
     e->mapped.clear();
     e->mailbox = nullptr; // was in allocs
     e->n_peers = e->peer_seq = e->send_floats = e->recv_floats = 0;
-    if (e->peer_err) *e->peer_err = 0;
+    if (e->dev_err) *e->dev_err = 0;
 }
 
 static inline uint32_t beam_stride(const sb_engine *e)
@@ -155,11 +155,13 @@ sb_status sb_create(const sb_options *opts, sb_engine **out)
         return SB_ERR_UNSUPPORTED;
     }
     if ((r = hipSetDevice(e->device)) != hipSuccess || (r = hipStreamCreate(&e->stream)) != hipSuccess ||
-        (r = hipEventCreate(&e->ev0)) != hipSuccess || (r = hipEventCreate(&e->ev1)) != hipSuccess) {
+        (r = hipEventCreate(&e->ev0)) != hipSuccess || (r = hipEventCreate(&e->ev1)) != hipSuccess ||
+        (r = hipHostMalloc((void **)&e->dev_err, 64, hipHostMallocMapped)) != hipSuccess) {
         g_create_error = std::string("HIP init failed: ") + hipGetErrorString(r);
         delete e;
         return SB_ERR_HIP;
     }
+    *e->dev_err = 0;
     *out = e;
     return SB_OK;
 }
@@ -170,7 +172,7 @@ sb_status sb_destroy(sb_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     free_scene(e);
-    if (e->peer_err) (void)hipHostFree(e->peer_err);
+    if (e->dev_err) (void)hipHostFree(e->dev_err);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -470,14 +472,19 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_TRY(dev_alloc(e, &e->d_rank, P));
         SB_TRY(dev_alloc(e, &e->d_rec, P));
         SB_TRY(dev_alloc(e, &e->d_cell_of, P));
-        SB_TRY(dev_alloc(e, &e->d_grid_ctl, 1));
+        SB_TRY(dev_alloc(e, &e->d_grid_ctl, 2));
         const size_t nblk = std::max<size_t>(e->ntiles, (P + 255) / 256) + 1;
-        SB_TRY(dev_alloc(e, &e->d_blk_max, nblk));
-        SB_HIP(e, hipMemset(e->d_blk_max, 0, nblk * 4));
-        SbGridCtl ctl{};
-        ctl.force = 1;
-        ctl.skin = skin;
-        SB_HIP(e, hipMemcpy(e->d_grid_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
+        for (int k = 0; k < 2; k++) {
+            SB_TRY(dev_alloc(e, &e->d_blk_max[k], nblk));
+            SB_HIP(e, hipMemset(e->d_blk_max[k], 0, nblk * 4));
+        }
+        SB_TRY(dev_alloc(e, &e->d_grid_bar, 1));
+        SB_HIP(e, hipMemset(e->d_grid_bar, 0, 4));
+        SbGridCtl ctl[2] = {};
+        ctl[0].force = ctl[1].force = 1;
+        ctl[0].skin = ctl[1].skin = skin;
+        SB_HIP(e, hipMemcpy(e->d_grid_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
+        e->grid_par = 0;
         e->grid.cell_start = e->d_cell_start;
         e->grid.rec = e->d_rec;
         e->grid.cell_of = e->d_cell_of;
@@ -562,10 +569,11 @@ sb_status sb_sync(sb_engine *e)
     if (!e) return SB_ERR_INVALID;
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
-    if (e->peer_err && *e->peer_err) {
-        uint32_t who = *e->peer_err;
-        *e->peer_err = 0;
-        SB_FAIL(e, SB_ERR_HIP, "peer exchange: neighbour(s) 0x%x did not signal within %u ms", who, e->peer_timeout_ms);
+    if (e->dev_err && *e->dev_err) {
+        const uint32_t what = *e->dev_err;
+        *e->dev_err = 0;
+        if (what & 0x80000000u) SB_FAIL(e, SB_ERR_HIP, "spatial hash build: device-wide barrier timed out (GPU oversubscribed?)");
+        SB_FAIL(e, SB_ERR_HIP, "peer exchange: neighbour(s) 0x%x did not signal within %u ms", what, e->peer_timeout_ms);
     }
     return SB_OK;
 }
@@ -716,14 +724,14 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "substeps_done") *value = e->substeps_done;
     else if (k == "lds_bytes") *value = e->lds_bytes;
     else if (k == "kernels_per_substep")
-        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 5 : 0);
+        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 1 : 0);
     else if (k == "grid_cells") *value = e->ncell;
     else if (k == "grid_builds") {
         *value = 0;
         if (e->d_grid_ctl) {
             SbGridCtl ctl;
             SB_HIP(e, hipStreamSynchronize(e->stream));
-            SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+            SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
             *value = ctl.builds;
         }
     }
@@ -847,10 +855,6 @@ sb_status sb_peer_mailbox(sb_engine *e, void **local_mailbox, void *ipc_handle, 
         SB_HIP(e, hipMemset(q, 0, bytes));
         SB_HIP(e, hipDeviceSynchronize());
         e->mailbox = q;
-        if (!e->peer_err) {
-            SB_HIP(e, hipHostMalloc((void **)&e->peer_err, 64, hipHostMallocMapped));
-            *e->peer_err = 0;
-        }
     }
     *local_mailbox = e->mailbox;
     if (mailbox_bytes) *mailbox_bytes = kMailboxFlagsBytes + 2 * mailbox_stride(e->recv_floats);

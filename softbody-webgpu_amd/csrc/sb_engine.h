@@ -75,7 +75,6 @@ struct sb_engine {
     uint32_t n_peers = 0, peer_seq = 0, peer_timeout_ms = 0;
     void *peer_box[8] = {};
     uint32_t peer_stride[8] = {}, peer_begin[8] = {}, peer_len[8] = {}, peer_dst[8] = {}, peer_slot[8] = {};
-    uint32_t *peer_err = nullptr;      // pinned host word the wait kernel sets when it gives up
 
     // tiled path
     uint32_t ntiles = 0, tile_cap_own = 0, tile_cap_all = 0;
@@ -103,8 +102,11 @@ struct sb_engine {
     uint32_t *d_rank = nullptr;       // per particle: arrival rank inside its cell
     uint32_t *d_cell_of = nullptr;    // per particle: cell at the last build
     float4 *d_rec = nullptr;          // records sorted by cell
-    SbGridCtl *d_grid_ctl = nullptr;  // rebuild decision state (device resident: no host sync per substep)
-    uint32_t *d_blk_max = nullptr;    // per workgroup of the particle kernel: largest displacement (float bits)
+    SbGridCtl *d_grid_ctl = nullptr;  // [2] rebuild decision state by substep parity (device resident: no host sync per substep)
+    uint32_t *d_blk_max[2] = {};      // per workgroup of the particle kernel: largest displacement (float bits), by parity
+    uint32_t *d_grid_bar = nullptr;   // arrival counter of k_grid_maintain's device-wide barrier
+    uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
+    uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)
 
     size_t device_bytes = 0;
     std::vector<void *> allocs;

@@ -352,102 +352,128 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
 }
 
 // ---------------------------------------------------------------- spatial hash build
+// ONE launch per substep (k_grid_maintain) in front of the particle kernel.  Every workgroup reduces the
+// previous substep's per-workgroup displacement maxima and takes the same decision (SbGridCtl,
+// sb_physics.h); on most substeps that is all and the kernel retires.  When the hash must be rebuilt the
+// SAME launch does it, as a persistent grid with device-wide barriers between the phases: count ->
+// block scan -> scan of the block sums -> scatter + absolute cell starts.  (Five separate launches that
+// each returned at once on 39 substeps out of 40 cost ~12 us per substep in launch boundaries alone.)
+// Decision state and the displacement slots are double buffered by substep parity: this launch reads
+// ctl[par] / blk_max[par] and publishes ctl[par^1]; the particle kernel that follows fills blk_max[par^1].
 
-// Four launches, each of which returns at once unless ctl->rebuild is set (by the last workgroup of
-// the previous substep's particle kernel, sb_track_displacement): count -> block scan -> scan of the
-// block sums -> scatter + absolute cell starts.  The count array is re-zeroed by the block scan, so no
-// separate clear is needed.
-
-// One workgroup reduces the per-workgroup displacement maxima of the substep just run and decides
-// whether the coming substep rebuilds the hash (SbGridCtl, sb_physics.h).  Everything it reads was
-// written by earlier launches: agent-scope loads only.
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_decide(SbGridCtl *ctl, uint32_t *blk_max, uint32_t nblk)
+// Device-wide barrier for a grid whose workgroups are all resident (<= SB_MAINTAIN_BLOCKS of 1024 threads, at most one per
+// CU, launched when the previous kernel of the stream has retired).  Monotone arrival counter; agent-scope
+// release before arriving and acquire after leaving make every workgroup's earlier writes visible to all
+// (the per-XCD L2s are not coherent for plain accesses).  The wait is bounded: on expiry the error word is
+// set and the workgroup moves on (a wrong hash and an error at the next sb_sync, never a hung wave).
+#define SB_MAINTAIN_BLOCKS 128u
+#define SB_MT 1024u               // threads per workgroup of k_grid_maintain: few fat workgroups, because every
+#define SB_MT_CHUNK (SB_MT * 8u)  // barrier arrival is an L2 write-back and its cost grows with the workgroup count
+#define SB_ERR_GRID_BARRIER 0x80000000u
+SB_DEV void sb_grid_barrier(uint32_t *bar, uint32_t target, uint32_t *err)
 {
-    __shared__ float s_wave_max[SB_BLOCK / 64];
-    float m = 0.0f;
-    for (uint32_t i = threadIdx.x; i < nblk; i += SB_BLOCK) {
-        m = fmaxf(m, __uint_as_float(SB_AGENT_LOAD(&blk_max[i])));
-        SB_AGENT_STORE(&blk_max[i], 0u);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63u) == 0u) s_wave_max[threadIdx.x >> 6] = m;
+    // every wave first drains its own stores into L2 (the workgroup barrier alone does not wait for them on
+    // this target); thread 0's release then writes the L2 back before it arrives
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) {
-        float step = 0.0f;
-        for (int w = 0; w < SB_BLOCK / 64; w++) step = fmaxf(step, s_wave_max[w]);
-        const float accum = SB_AGENT_LOAD(&ctl->accum) + step; // bound for the READ state of this substep
-        const bool rebuild = SB_AGENT_LOAD(&ctl->force) != 0u || !(accum <= SB_AGENT_LOAD(&ctl->skin)); // NaN-safe
-        SB_AGENT_STORE(&ctl->force, 0u);
-        SB_AGENT_STORE(&ctl->rebuild, rebuild ? 1u : 0u);
-        SB_AGENT_STORE(&ctl->accum, rebuild ? 0.0f : accum);
-        if (rebuild) SB_AGENT_STORE(&ctl->builds, SB_AGENT_LOAD(&ctl->builds) + 1u);
-    }
-}
-
-// counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
-// per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_count(const float2 *__restrict__ pos, uint32_t P, SbGrid g,
-                                                         uint32_t *cell_cnt, uint32_t *cell_of, uint32_t *rank,
-                                                         const SbGridCtl *ctl)
-{
-    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
-    uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    float2 p = pos[i];
-    uint32_t c = sb_grid_coord(p.y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p.x, g.x0, g.cell, g.nx);
-    cell_of[i] = c;
-    rank[i] = atomicAdd(&cell_cnt[c], 1u);
-}
-
-// exclusive scan of each 2048-cell block (256 threads x 8 cells) + the block totals; clears the counts
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_blocks(uint32_t *cell_cnt, uint32_t *cell_scan, uint32_t n,
-                                                               uint32_t *block_sum, const SbGridCtl *ctl)
-{
-    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
-    __shared__ uint32_t s_wave[SB_BLOCK / 64];
-    const uint32_t tid = threadIdx.x, base = blockIdx.x * SB_SCAN_BLOCK + tid * 8u;
-    uint32_t v[8], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        uint32_t x = 0u;
-        if (base + k < n) {
-            x = cell_cnt[base + k];
-            cell_cnt[base + k] = 0u; // ready for the next build
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (wall_clock64() - t0 > 200000000ull) { // 2 s at 100 MHz
+                __hip_atomic_fetch_or(err, SB_ERR_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(24); // ~0.7 us between polls: hundreds of pollers on one address slow the arrivals down
         }
-        v[k] = sum;
-        sum += x;
     }
-    // inclusive scan of the per-thread sums across the wave, then across the 4 waves
-    uint32_t inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(inc, off, 64);
-        if ((tid & 63u) >= (uint32_t)off) inc += t;
-    }
-    if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
     __syncthreads();
-    uint32_t wave_off = 0;
-    for (uint32_t w = 0; w < (tid >> 6); w++) wave_off += s_wave[w];
-    const uint32_t excl = wave_off + inc - sum;
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (base + k < n) cell_scan[base + k] = v[k] + excl;
-    if (tid == SB_BLOCK - 1) block_sum[blockIdx.x] = excl + sum;
 }
 
-// exclusive scan of the block totals, one workgroup walking 256 at a time with a carry
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum, uint32_t nblocks, const SbGridCtl *ctl)
+struct SbGridBuild {
+    uint32_t *cell_cnt, *cell_scan, *block_off, *rank, *cell_of, *cell_start;
+    float4 *rec;
+    uint32_t ncell1, nchunks;
+    uint32_t *bar, *err;
+};
+
+__global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const uint32_t *blk_max, uint32_t nblk,
+                                                            uint32_t par, const float2 *__restrict__ pos,
+                                                            const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
+                                                            SbGridBuild w)
 {
-    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
-    __shared__ uint32_t s_wave[SB_BLOCK / 64];
+    __shared__ float s_wave_max[SB_MT / 64];
+    __shared__ uint32_t s_wave[SB_MT / 64];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
+    // ---- decision, identical in every workgroup (everything read here was written by earlier launches)
+    const SbGridCtl *cin = ctl + par;
+    const float skin = SB_AGENT_LOAD(&cin->skin), accum_in = SB_AGENT_LOAD(&cin->accum); // in flight with the slots
+    const uint32_t builds = SB_AGENT_LOAD(&cin->builds), force = SB_AGENT_LOAD(&cin->force);
+    float m = 0.0f;
+    for (uint32_t i = tid; i < nblk; i += SB_MT) m = fmaxf(m, __uint_as_float(SB_AGENT_LOAD(&blk_max[i])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63u) == 0u) s_wave_max[tid >> 6] = m;
     __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += SB_BLOCK) {
-        uint32_t x = base + tid < nblocks ? block_sum[base + tid] : 0u;
-        uint32_t inc = x;
+    float step = 0.0f;
+    for (int k = 0; k < SB_MT / 64; k++) step = fmaxf(step, s_wave_max[k]);
+    const float accum = accum_in + step; // bound for the READ state of this substep
+    const bool rebuild = force != 0u || !(accum <= skin); // NaN-safe
+    if (blockIdx.x == 0 && tid == 0) {
+        SbGridCtl *cout = ctl + (par ^ 1u);
+        SB_AGENT_STORE(&cout->rebuild, rebuild ? 1u : 0u);
+        SB_AGENT_STORE(&cout->force, 0u);
+        SB_AGENT_STORE(&cout->accum, rebuild ? 0.0f : accum);
+        SB_AGENT_STORE(&cout->skin, skin);
+        SB_AGENT_STORE(&cout->builds, builds + (rebuild ? 1u : 0u));
+    }
+    if (!rebuild) return;
+
+    const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
+    const uint32_t bar0 = builds * 3u * gridDim.x; // arrivals before this build (three barriers per build)
+    // ---- counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
+    // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
+    // (four particles per thread and round, so that four returning atomics are in flight per lane)
+    for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
+        uint32_t c[4], rk[4];
+        float2 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthreads;
+            p[u] = i < P ? pos[i] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            c[u] = sb_grid_coord(p[u].y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p[u].x, g.x0, g.cell, g.nx);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + (uint32_t)u * nthreads < P) rk[u] = atomicAdd(&w.cell_cnt[c[u]], 1u);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthreads;
+            if (i < P) {
+                w.cell_of[i] = c[u];
+                w.rank[i] = rk[u];
+            }
+        }
+    }
+    sb_grid_barrier(w.bar, bar0 + gridDim.x, w.err);
+    // ---- exclusive scan of each 8192-cell chunk (1024 threads x 8 cells) + the chunk totals; clears the counts
+    for (uint32_t chunk = blockIdx.x; chunk < w.nchunks; chunk += gridDim.x) {
+        const uint32_t base = chunk * SB_MT_CHUNK + tid * 8u;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t x = 0u;
+            if (base + k < w.ncell1) {
+                x = SB_AGENT_LOAD(&w.cell_cnt[base + k]);
+                w.cell_cnt[base + k] = 0u; // ready for the next build
+            }
+            v[k] = sum;
+            sum += x;
+        }
+        uint32_t inc = sum; // inclusive scan of the per-thread sums across the wave, then across the 16 waves
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             uint32_t t = __shfl_up(inc, off, 64);
@@ -455,33 +481,61 @@ __global__ __launch_bounds__(SB_BLOCK) void k_grid_scan_sums(uint32_t *block_sum
         }
         if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
         __syncthreads();
-        uint32_t wave_off = s_carry;
-        for (uint32_t w = 0; w < (tid >> 6); w++) wave_off += s_wave[w];
-        if (base + tid < nblocks) block_sum[base + tid] = wave_off + inc - x;
-        __syncthreads();
-        if (tid == SB_BLOCK - 1) s_carry = wave_off + inc;
+        uint32_t wave_off = 0;
+        for (uint32_t k = 0; k < (tid >> 6); k++) wave_off += s_wave[k];
+        const uint32_t excl = wave_off + inc - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (base + k < w.ncell1) w.cell_scan[base + k] = v[k] + excl;
+        if (tid == SB_MT - 1) w.block_off[chunk] = excl + sum;
         __syncthreads();
     }
-}
-
-// particles -> records sorted by cell, and the absolute first-record index of every cell
-__global__ __launch_bounds__(SB_BLOCK) void k_grid_scatter(const float2 *__restrict__ pos,
-                                                           const uint32_t *__restrict__ pslot, uint32_t P,
-                                                           const uint32_t *__restrict__ cell_of,
-                                                           const uint32_t *__restrict__ cell_scan,
-                                                           const uint32_t *__restrict__ block_off,
-                                                           const uint32_t *__restrict__ rank, float4 *rec,
-                                                           uint32_t *cell_start, uint32_t ncell1, const SbGridCtl *ctl)
-{
-    if (!SB_AGENT_LOAD(&ctl->rebuild)) return;
-    const uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (i < P) {
-        const uint32_t c = cell_of[i];
-        const float2 p = pos[i];
-        rec[cell_scan[c] + block_off[c / SB_SCAN_BLOCK] + rank[i]] =
-            make_float4(p.x, p.y, __uint_as_float(pslot[i]), __uint_as_float(i));
+    sb_grid_barrier(w.bar, bar0 + 2u * gridDim.x, w.err);
+    // ---- exclusive scan of the chunk totals: one workgroup walking 1024 at a time with a carry
+    if (blockIdx.x == 0) {
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < w.nchunks; base += SB_MT) {
+            const uint32_t x = base + tid < w.nchunks ? w.block_off[base + tid] : 0u;
+            uint32_t inc = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t t = __shfl_up(inc, off, 64);
+                if ((tid & 63u) >= (uint32_t)off) inc += t;
+            }
+            if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
+            __syncthreads();
+            uint32_t wave_off = s_carry;
+            for (uint32_t k = 0; k < (tid >> 6); k++) wave_off += s_wave[k];
+            if (base + tid < w.nchunks) w.block_off[base + tid] = wave_off + inc - x;
+            __syncthreads();
+            if (tid == SB_MT - 1) s_carry = wave_off + inc;
+            __syncthreads();
+        }
     }
-    for (uint32_t c = i; c < ncell1; c += gridDim.x * SB_BLOCK) cell_start[c] = cell_scan[c] + block_off[c / SB_SCAN_BLOCK];
+    sb_grid_barrier(w.bar, bar0 + 3u * gridDim.x, w.err);
+    // ---- particles -> records sorted by cell, and the absolute first-record index of every cell
+    for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
+        uint32_t c[4], at[4], slot[4];
+        float2 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthreads;
+            const bool in = i < P;
+            c[u] = in ? w.cell_of[i] : 0u;
+            p[u] = in ? pos[i] : make_float2(0.f, 0.f);
+            at[u] = in ? w.rank[i] : 0u;
+            slot[u] = in ? pslot[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) at[u] += w.cell_scan[c[u]] + w.block_off[c[u] / SB_MT_CHUNK];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthreads;
+            if (i < P) w.rec[at[u]] = make_float4(p[u].x, p[u].y, __uint_as_float(slot[u]), __uint_as_float(i));
+        }
+    }
+    for (uint32_t c = gtid; c < w.ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -632,25 +686,30 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
     const uint32_t mode = e->opt.collision_mode;
     if (mode == SB_COLLIDE_GRID && e->P) {
-        // (re)build the spatial hash from the READ state when the displacement bound demands it
-        const uint32_t n = e->ncell + 1, nblocks = cdiv(n, SB_SCAN_BLOCK), pb = cdiv(e->P, SB_BLOCK);
-        k_grid_decide<<<1, SB_BLOCK, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max, e->path == SB_PATH_TILED ? e->ntiles : pb);
-        k_grid_count<<<pb, SB_BLOCK, 0, e->stream>>>(r.pos, e->P, e->grid, e->d_cell_cnt, e->d_cell_of, e->d_rank,
-                                                     e->d_grid_ctl);
-        k_grid_scan_blocks<<<nblocks, SB_BLOCK, 0, e->stream>>>(e->d_cell_cnt, e->d_cell_scan, n, e->d_block_off,
-                                                                e->d_grid_ctl);
-        k_grid_scan_sums<<<1, SB_BLOCK, 0, e->stream>>>(e->d_block_off, nblocks, e->d_grid_ctl);
-        k_grid_scatter<<<pb, SB_BLOCK, 0, e->stream>>>(r.pos, e->d_pslot, e->P, e->d_cell_of, e->d_cell_scan,
-                                                       e->d_block_off, e->d_rank, e->d_rec, e->d_cell_start, n,
-                                                       e->d_grid_ctl);
+        // decide, and when the displacement bound demands it rebuild the spatial hash from the READ state
+        const uint32_t n = e->ncell + 1, nchunks = cdiv(n, SB_MT_CHUNK);
+        const uint32_t nblk = e->path == SB_PATH_TILED ? e->ntiles : cdiv(e->P, SB_BLOCK);
+        const uint32_t work = std::max(cdiv(e->P, SB_MT), nchunks);
+        static const uint32_t max_blocks = [] { // tuning knob; every workgroup must be resident at once (see sb_grid_barrier)
+            const char *v = getenv("SB_MAINTAIN_BLOCKS");
+            const long n = v ? atol(v) : 0;
+            return n >= 1 && n <= 2048 ? (uint32_t)n : SB_MAINTAIN_BLOCKS;
+        }();
+        const uint32_t blocks = std::min(std::max(work, 1u), max_blocks);
+        SbGridBuild gb{e->d_cell_cnt, e->d_cell_scan, e->d_block_off, e->d_rank, e->d_cell_of, e->d_cell_start,
+                       e->d_rec, n, nchunks, e->d_grid_bar, e->dev_err};
+        k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
+                                                            r.pos, e->d_pslot, e->P, e->grid, gb);
+        e->grid_par ^= 1u;
     }
+    uint32_t *blk_out = e->d_blk_max[e->grid_par]; // the slots the NEXT maintain launch reads
     if (e->path == SB_PATH_ATOMIC) {
         if (e->nbeam)
             k_beams_atomic<<<cdiv(e->nbeam, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->beams, e->nbeam, r.pos,
                                                                                e->d_forces, e->d_broken);
         if (e->P) {
             dim3 g(cdiv(e->P, SB_BLOCK));
-#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, e->d_blk_max)
+#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, blk_out)
             if (mode == SB_COLLIDE_ALLPAIRS) SB_LAUNCH_P(SB_COLLIDE_ALLPAIRS);
             else if (mode == SB_COLLIDE_GRID) SB_LAUNCH_P(SB_COLLIDE_GRID);
             else SB_LAUNCH_P(SB_COLLIDE_OFF);
@@ -660,7 +719,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_TILE_BLOCK, e->lds_bytes, e->stream>>>(            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
         e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
-        e->d_blk_max, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+        blk_out, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
 #define SB_LAUNCH_TA(M, T) do { if (write_aux) SB_LAUNCH_T(M, T, true); else SB_LAUNCH_T(M, T, false); } while (0)
 #define SB_LAUNCH_TM(M) do { if (e->mat_mode == 2) SB_LAUNCH_TA(M, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(M, 1); else SB_LAUNCH_TA(M, 0); } while (0)
         if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(SB_COLLIDE_GRID);
@@ -696,7 +755,10 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
     k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->d_ghost_p_off,
                                                                 e->n_ghost_p, e->d_ghost_b, e->d_ghost_b_off,
                                                                 e->n_ghost_b_copies, src);
-    if (e->d_grid_ctl) (void)hipMemsetAsync(&e->d_grid_ctl->force, 0x01, 4, e->stream); // ghosts jumped: rebin
+    if (e->d_grid_ctl) { // ghosts jumped: rebin (both parities: whichever the next maintain launch reads)
+        (void)hipMemsetAsync(&e->d_grid_ctl[0].force, 0x01, 4, e->stream);
+        (void)hipMemsetAsync(&e->d_grid_ctl[1].force, 0x01, 4, e->stream);
+    }
     // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
     if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);
 }
@@ -722,7 +784,7 @@ void sbk_launch_peer_exchange(sb_engine *e)
     }
     sig.local = (uint32_t *)e->mailbox;
     sig.limit_ticks = (uint64_t)e->peer_timeout_ms * 100000ull;
-    sig.err = e->peer_err;
+    sig.err = e->dev_err;
     uint32_t n = 3 * e->n_send_p + e->n_send_b;
     if (n)
         k_halo_pack_peer<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p,

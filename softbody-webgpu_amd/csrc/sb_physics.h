@@ -246,7 +246,7 @@ struct SbGrid {
 // cannot be in contact: candidates are found in the stale cells, pre-filtered on their stale
 // positions and tested exactly at their CURRENT positions.
 struct SbGridCtl {
-    uint32_t rebuild; // 1: the build kernels of this substep must run (written by k_grid_decide)
+    uint32_t rebuild; // 1: the last k_grid_maintain launch rebuilt the hash (informational)
     uint32_t force;   // set by the host (upload, halo unpack): rebuild unconditionally
     float accum;      // D for the READ state of the coming substep
     float skin;
@@ -260,7 +260,7 @@ struct SbGridCtl {
 // End of the particle kernel, called by EVERY thread of the block: this block's largest displacement
 // goes to blk_max[blockIdx.x] (float bits; anything not provably small, NaN included, reads as huge).
 // One plain slot per workgroup: funnelling ~1000 workgroups through atomics on one address cost
-// ~50 us per launch (same-address atomics retire one per ~12 ns).  k_grid_decide reduces the slots.
+// ~50 us per launch (same-address atomics retire one per ~12 ns).  k_grid_maintain reduces the slots.
 SB_DEV void sb_store_block_displacement(uint32_t *blk_max, float m)
 {
     __shared__ float s_wave_max[SB_MAX_WAVES];
