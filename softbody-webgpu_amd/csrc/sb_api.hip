@@ -489,6 +489,14 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.rec = e->d_rec;
         e->grid.cell_of = e->d_cell_of;
         e->grid.skin = skin;
+        SB_TRY(dev_alloc(e, &e->d_nl_count, P));
+        SB_TRY(dev_alloc(e, &e->d_nl, (size_t)SB_NL_CAP * std::max<size_t>(P, 1)));
+        SB_HIP(e, hipMemset(e->d_nl_count, 0, std::max<size_t>(P, 1) * 4));
+        e->grid.nl_count = e->d_nl_count;
+        e->grid.nl = e->d_nl;
+        e->grid.nl_stride = P;
+        const float reach = e->prm.particle_radius * 2.0f + 2.0f * skin;
+        e->nl_reach2 = reach * reach * 1.001f;
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     if (e->path == SB_PATH_ATOMIC) {

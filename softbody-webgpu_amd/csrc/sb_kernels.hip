@@ -86,10 +86,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
             }
         }
     }
-    if (MODE == SB_COLLIDE_GRID && active) {
-        const SbGridRanges rg = sb_grid_ranges(grid, grid.cell_of[i]);
-        sb_collide_grid(grid, rg, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
-    }
+    if (MODE == SB_COLLIDE_GRID && active)
+        sb_collide_list(grid, grid.nl_count[i], prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
     float moved = 0.0f;
     if (active) {
         int2 f = forces[i];
@@ -197,18 +195,14 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
     }
     if (MAT != 0)
         for (uint32_t i = tid; i < nmat * SB_MAT_ROW; i += SB_TILE_BLOCK) s_mat[i] = mat_tab[i];
-    // SB_COLLIDE_GRID: the record ranges of each particle's three cell rows are fetched here, so the two
-    // dependent lookups (particle -> stale cell -> cell starts) are long done when phase 2 needs them
-    SbGridRanges rg[SB_UNROLL];
+    // SB_COLLIDE_GRID: the length of each particle's neighbour list is fetched here, long before phase 2 walks it
+    uint32_t ncand[SB_UNROLL];
     if (MODE == SB_COLLIDE_GRID) {
-        uint32_t qcell[SB_UNROLL];
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
             const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
-            qcell[u] = grid.cell_of[p0 + (i < n_own ? i : 0u)];
+            ncand[u] = i < n_own ? grid.nl_count[p0 + i] : 0u;
         }
-#pragma unroll
-        for (int u = 0; u < SB_UNROLL; u++) rg[u] = sb_grid_ranges(grid, qcell[u]);
     }
     __syncthreads();
 
@@ -306,7 +300,7 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
     // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
     bool any_acc = false;
     float moved = 0.0f;
-    auto finish = [&](uint32_t i, float2 vel, float2 acc, const SbGridRanges &ranges) {
+    auto finish = [&](uint32_t i, float2 vel, float2 acc, uint32_t count) {
         const uint32_t g = p0 + i;
         SbParticle particle;
         particle.p = s_pos[i];
@@ -316,7 +310,7 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
         if (MODE == SB_COLLIDE_GRID) {
             const SbParticle self = particle; // :141
 #if !(SB_ABLATE & 64) // diagnostic build: no collision scan
-            sb_collide_grid(grid, ranges, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx,
+            sb_collide_list(grid, count, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx,
                             r.pos, r.vel);
 #endif
         }
@@ -337,12 +331,11 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
 #pragma unroll
     for (int u = 0; u < SB_UNROLL; u++) {
         const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
-        if (i < n_own) finish(i, pv[u], pa[u], rg[u]);
+        if (i < n_own) finish(i, pv[u], pa[u], MODE == SB_COLLIDE_GRID ? ncand[u] : 0u);
     }
     for (uint32_t i = tid + SB_UNROLL * SB_TILE_BLOCK; i < n_own; i += SB_TILE_BLOCK) {
-        SbGridRanges tail{};
-        if (MODE == SB_COLLIDE_GRID) tail = sb_grid_ranges(grid, grid.cell_of[p0 + i]);
-        finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f), tail);
+        finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f),
+               MODE == SB_COLLIDE_GRID ? grid.nl_count[p0 + i] : 0u);
     }
 #if !(SB_ABLATE & 128) // diagnostic build: no displacement tracking
     if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
@@ -395,6 +388,8 @@ struct SbGridBuild {
     float4 *rec;
     uint32_t ncell1, nchunks;
     uint32_t *bar, *err;
+    uint32_t *nl_count, *nl;
+    float list_reach2;
 };
 
 __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const uint32_t *blk_max, uint32_t nblk,
@@ -431,7 +426,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     if (!rebuild) return;
 
     const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
-    const uint32_t bar0 = builds * 3u * gridDim.x; // arrivals before this build (three barriers per build)
+    const uint32_t bar0 = builds * 4u * gridDim.x; // arrivals before this build (four barriers per build)
     // ---- counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
     // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
     // (four particles per thread and round, so that four returning atomics are in flight per lane)
@@ -536,6 +531,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         }
     }
     for (uint32_t c = gtid; c < w.ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
+    sb_grid_barrier(w.bar, bar0 + 4u * gridDim.x, w.err);
+    // ---- neighbour lists from the fresh hash: what the particle kernels walk until the next build
+    for (uint32_t i = gtid; i < P; i += nthreads) sb_neighbour_list_build(g, w.nl_count, w.nl, i, pos[i], w.list_reach2);
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -697,7 +695,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
         }();
         const uint32_t blocks = std::min(std::max(work, 1u), max_blocks);
         SbGridBuild gb{e->d_cell_cnt, e->d_cell_scan, e->d_block_off, e->d_rank, e->d_cell_of, e->d_cell_start,
-                       e->d_rec, n, nchunks, e->d_grid_bar, e->dev_err};
+                       e->d_rec, n, nchunks, e->d_grid_bar, e->dev_err, e->d_nl_count, e->d_nl, e->nl_reach2};
         k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
                                                             r.pos, e->d_pslot, e->P, e->grid, gb);
         e->grid_par ^= 1u;

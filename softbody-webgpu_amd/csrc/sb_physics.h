@@ -236,7 +236,14 @@ struct SbGrid {
     const uint32_t *cell_of;    // per particle: its cell at the last build
     float x0, y0, cell, skin;
     uint32_t nx, ny;
+    // neighbour lists, made at build time (sb_neighbour_list_build): per particle the internal indices of
+    // everybody within 2r + 2*skin, in ascending slot order; entry k of particle i at nl[k * nl_stride + i]
+    const uint32_t *nl_count;   // entries, or SB_NL_OVERFLOW: more than SB_NL_CAP, scan the cells instead
+    const uint32_t *nl;
+    uint32_t nl_stride;
 };
+#define SB_NL_CAP 16u
+#define SB_NL_OVERFLOW 0xFFFFFFFFu
 // The hash is rebuilt only when needed.  Cells are 2r*(1+1/64) + 2*skin wide; the engine keeps a bound
 // D on how far any particle can have moved since the last build (the sum of the per-substep maximum
 // displacements) and rebuilds before a substep whose READ state has D > skin.  While D <= skin, two
@@ -355,6 +362,69 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbPar
         sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[best_id], best_p, vel_r[best_id]);
         last = best_slot;
         have_last = true;
+    }
+}
+
+// Build time (positions in the records are current): everybody within `reach` = 2r + 2*skin of particle i,
+// in ascending slot order (repeated selection of the smallest slot above the last one taken, as above).
+// While the displacement bound D <= skin, a pair closer than 2r NOW was closer than 2r + 2D at build time,
+// so the list is a superset of i's contacts until the next build.  NaN distances are kept (conservative).
+SB_DEV void sb_neighbour_list_build(const SbGrid &g, uint32_t *nl_count, uint32_t *nl, uint32_t i, float2 p,
+                                    float reach2)
+{
+    const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
+    uint32_t n = 0u, last = 0u;
+    bool have_last = false;
+    for (;;) {
+        uint32_t best_slot = 0xFFFFFFFFu, best_id = 0u;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            for (uint32_t k = rg.b[r]; k < rg.e[r]; k++) {
+                const float4 rc = g.rec[k];
+                const uint32_t slot = __float_as_uint(rc.z), id = __float_as_uint(rc.w);
+                if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
+                const float dx = rc.x - p.x, dy = rc.y - p.y;
+                if (dx * dx + dy * dy > reach2) continue;
+                best_slot = slot;
+                best_id = id;
+            }
+        }
+        if (best_slot == 0xFFFFFFFFu) break;
+        if (n == SB_NL_CAP) {
+            n = SB_NL_OVERFLOW;
+            break;
+        }
+        nl[n * g.nl_stride + i] = best_id;
+        n++;
+        last = best_slot;
+        have_last = true;
+    }
+    nl_count[i] = n;
+}
+
+// The collision loop of compute.wgsl:144-170 over particle i's neighbour list (`count` = nl_count[i], fetched
+// by the caller ahead of time).  The list is slot-sorted and every test uses the frozen copy `self`, so
+// walking it and applying the contacts found is the ascending-slot order of the all-pairs scan.
+SB_DEV void sb_collide_list(const SbGrid &g, uint32_t count, const SbParams &prm, float friction,
+                            float elasticity_coeff, SbParticle &particle, const SbParticle &self, uint32_t i,
+                            const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
+                            const float2 *__restrict__ vel_r)
+{
+    if (count == SB_NL_OVERFLOW) { // a pile denser than the list holds: scan the cells
+        const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
+        sb_collide_grid(g, rg, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
+        return;
+    }
+    const float two_r = prm.particle_radius * 2.0f;
+    const float far2 = two_r * two_r * 1.001f;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t id = g.nl[k * g.nl_stride + i];
+        const float2 q = pos_r[id];
+        const float ex = q.x - self.p.x, ey = q.y - self.p.y;
+        const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
+        if (d2 > far2) continue;            // sqrt is monotone: cannot give d < 2r, and is not 0
+        const float d = sb_sqrt(d2);
+        if (d == 0.0f || d < two_r) sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[id], q, vel_r[id]);
     }
 }
 

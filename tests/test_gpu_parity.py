@@ -210,6 +210,25 @@ def test_grid_particle_soup(sb, oracle, path):
     assert not np.array_equal(got.particles[:, 2:4], pts[:, 2:4])
 
 
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_dense_pile_overflows_neighbour_lists(sb, oracle, path):
+    """80 particles thrown into a 30x30 patch (plus three on one spot): every one of them has far more than
+    SB_NL_CAP = 16 others within 2r + 2*skin, so their neighbour lists overflow and the kernels must fall back
+    to scanning the cells -- while 400 spread-out particles around them use their lists.  Bits of all-pairs."""
+    rng = np.random.default_rng(23)
+    P = 480
+    pts = np.zeros((P, 6), "f4")
+    pts[:80, :2] = rng.uniform(600, 630, (80, 2))
+    pts[5, :2] = pts[4, :2] = pts[3, :2]
+    pts[80:, :2] = rng.uniform(10, 1390, (P - 80, 2))
+    pts[:, 2:4] = rng.uniform(-3, 3, (P, 2))
+    buf = sb.Buffers(2, P, 4)
+    buf.set_scene(pts, np.zeros(0, sb.layout.BEAM_DTYPE[2]))
+    got, exp, _ = run_both(sb, oracle, buf, n=48, mode=GRID, ref_mode=ALLPAIRS, path=path, bounds=1400.0, tile=128)
+    assert np.isfinite(exp.particles).all()
+    assert_same(got, exp, "dense pile path %d" % path)
+
+
 def two_blob_scene(sb):
     """Blob A (64x32 lattice) resting on the floor, blob B (48x24) dropped onto it, 300 free
     particles raining in: beams + inter-blob contacts + floor/wall response together."""
