@@ -29,9 +29,11 @@ static thread_local std::string g_create_error;
 #define SB_HIP(e, call)                                                                       \
     do {                                                                                      \
         hipError_t _r = (call);                                                               \
-        if (_r != hipSuccess)                                                                 \
+        if (_r != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* reported here: must not resurface in a later launch check */ \
             SB_FAIL(e, _r == hipErrorOutOfMemory ? SB_ERR_OOM : SB_ERR_HIP, "%s failed: %s",  \
                     #call, hipGetErrorString(_r));                                            \
+        }                                                                                     \
     } while (0)
 
 template <typename T>
