@@ -406,7 +406,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     const float skin = SB_AGENT_LOAD(&cin->skin), accum_in = SB_AGENT_LOAD(&cin->accum); // in flight with the slots
     const uint32_t builds = SB_AGENT_LOAD(&cin->builds), force = SB_AGENT_LOAD(&cin->force);
     float m = 0.0f;
-    for (uint32_t i = tid; i < nblk; i += SB_MT) m = fmaxf(m, __uint_as_float(SB_AGENT_LOAD(&blk_max[i])));
+    for (uint32_t i = tid; i < nblk; i += SB_MT) m = fmaxf(m, __uint_as_float(blk_max[i])); // per-lane addresses: vector loads
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((tid & 63u) == 0u) s_wave_max[tid >> 6] = m;

@@ -53,6 +53,12 @@ if os.path.exists(bg):
     shutil.copy(bg, os.path.join(dst, "%s_bench_grid.json" % tag))
     summary["bench_grid"] = json.loads(open(bg).read().strip().splitlines()[-1])
 
+for name, out in (("exchange_cost.txt", "%s_exchange_cost.txt"), ("rehearse_2ranks.json", "%s_rehearse_2ranks_one_gpu.json"),
+                  ("node_bench.json", "%s_node_bench.json")):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, out % tag))
+
 calib = {}
 for which, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
     for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
