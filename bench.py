@@ -195,8 +195,9 @@ def main():
                                     depth=a.ghost_depth)
     if a.mixed_stiffness:
         if plan is not None:
-            sys.exit("--mixed-stiffness is a single-GPU option (slab scenes draw per-rank beam lists)")
-        sb.scenes.mix_stiffness(buf, subticks=a.subticks)
+            halo.mix_stiffness(buf, plan, subticks=a.subticks)   # keyed by global beam id: ghosts match their owners
+        else:
+            sb.scenes.mix_stiffness(buf, subticks=a.subticks)
     P_local = buf.particle_count if plan is None else plan.n_owned
     B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2,

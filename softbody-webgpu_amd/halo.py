@@ -133,6 +133,19 @@ def slab_scene(sb, rank, world, W, H, d=30.0, origin=(1000.0, 1000.0), jitter=0.
     return buf, plan
 
 
+def mix_stiffness(buf, plan, seed=1, subticks=128):
+    """scenes.mix_stiffness for slab scenes (BASELINE config 5 across ranks): the draw is keyed by the GLOBAL
+    beam key, so a ghost copy of a beam gets exactly its owner's spring and damping."""
+    B = buf.beam_count
+    u = hash_at(seed + 77, plan.global_beam_key[:B])
+    pick = ((u + 1.0) * 2.0).astype(np.int64).clip(0, 3)
+    springs = np.array([1.0, 3.0, 50.0, 500.0], dtype="<f4")[pick]
+    damp_cap = np.float32(0.5 / 6.0 * subticks * subticks)
+    buf.beams["spring"][:B] = springs
+    buf.beams["damp"][:B] = np.minimum(springs * np.float32(14.0), damp_cap).astype("<f4")
+    return buf
+
+
 class Exchanger:
     """Steps one rank's engine and refreshes its ghost zone every `plan.depth` substeps.
 

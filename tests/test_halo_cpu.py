@@ -115,6 +115,39 @@ def test_peer_exchanger_routing_equals_single_engine(sb, oracle, world, depth):
         assert beams[int(k)].tobytes()[8:] == rec.tobytes()[8:], "beam %d" % k
 
 
+def test_mixed_stiffness_slabs_equal_single_engine(sb, oracle):
+    """BASELINE config 5 across ranks: springs drawn per GLOBAL beam key, so ghost copies carry their owners'
+    parameters and the sharded run stays bit-identical to the unsharded one."""
+    from halo_oracle import LocalBus, OracleRank, step_all
+    halo = sb.halo
+    W, H, world, depth, steps = 6, 7, 3, 2, 30
+    kw = dict(d=25.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0))
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    halo.mix_stiffness(gbuf, gplan, subticks=64)
+    assert len(set(gbuf.beams["spring"][:gbuf.beam_count].tolist())) == 4
+    ref = OracleRank(oracle, gbuf, 1000.0)
+    ref.step(steps)
+    want = ref.load(gbuf)
+    bus = LocalBus()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        halo.mix_stiffness(buf, plan, subticks=64)
+        eng = OracleRank(oracle, buf, 1000.0)
+        tr = bus.transport(r, lambda a, b: (np.zeros(max(a, 1), "f4"), np.zeros(max(b, 1), "f4")), lambda t: t)
+        exs.append(halo.Exchanger(eng, plan, tr))
+        made.append((buf, plan, eng))
+
+    def copy(dst, src):
+        dst[:] = src
+
+    step_all(exs, bus, steps, copy)
+    parts, beams = merged_state([(plan, eng.load(buf)) for buf, plan, eng in made], W * world * H, None)
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)].tobytes()[8:] == rec.tobytes()[8:], "beam %d" % k
+
+
 def test_without_refresh_ghost_zone_goes_stale(sb, oracle):
     """Negative control: skipping the exchange must change the owned result (the test above is
     sensitive to the halo logic)."""

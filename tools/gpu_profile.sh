@@ -20,6 +20,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calib_writ
 # config 3 (grid collisions): bench line + kernel trace
 python3 $OLDPWD/bench.py --collisions grid --no-cpu-baseline > $OUT/bench_grid.json 2> $OUT/bench_grid.err || { echo grid bench failed; tail -5 $OUT/bench_grid.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grid -- python3 $OLDPWD/bench.py --collisions grid --steps 200 --warmup 16 --no-cpu-baseline > $OUT/trace_grid.log 2>&1 || { echo grid trace failed; exit 1; }
+# one GPU's share of BASELINE configs 4 (500 x 4000 columns x rows) and 5 (1000 x 8000, mixed springs, dt = 1/128)
+python3 $OLDPWD/bench.py --no-cpu-baseline --width 500 --height 4000 --steps 500 > $OUT/cfg4_share.json 2>/dev/null || echo "cfg4 share failed"
+python3 $OLDPWD/bench.py --no-cpu-baseline --width 1000 --height 8000 --mixed-stiffness --subticks 128 --steps 200 --warmup 32 > $OUT/cfg5_share.json 2>/dev/null || echo "cfg5 share failed"
 # multi-GPU pieces that one card can show: cost of one ghost refresh (RCCL vs direct peer stores, loopback)
 # and the whole N=2 bench code path with both ranks on this card (rehearsal, not a measurement)
 python3 $OLDPWD/tools/exchange_cost.py 2>/dev/null | grep "^depth" > $OUT/exchange_cost.txt || echo "exchange cost probe failed"
