@@ -145,6 +145,19 @@ def peer_exchanger(halo, eng, plan, buf, dist, torch, ctl):
         except Exception as exc:  # noqa: BLE001
             why, ok = "check: %r" % (exc,), False
         ok = vote(ok)
+    if ok:
+        # ... and then in motion: three refresh periods (the third reuses the first receive buffer), after which
+        # every ghost record must equal its owner's, compared over torch.distributed (not over the mailboxes)
+        try:
+            ex.step(3 * plan.depth)
+            eng.sync()
+            bad = halo.ghost_mismatches(plan, eng.load_buffers(buf.copy()), dist, torch, torch.device(ctl))
+            if bad:
+                why = "check: %d ghost records differ from their owners after three refreshes" % bad
+            ok = bad == 0
+        except Exception as exc:  # noqa: BLE001
+            why, ok = "check: %r" % (exc,), False
+        ok = vote(ok)
     if why:
         print("[bench rank %d] direct peer exchange unavailable (%s)" % (dist.get_rank(), why), file=sys.stderr, flush=True)
     dist.barrier()
@@ -215,6 +228,7 @@ def main():
             if a.rehearse_one_gpu:
                 sys.exit("--rehearse-one-gpu: the peer exchange could not be set up and RCCL cannot share one GPU")
             if a.exchange == "peer":
+                eng.sync_quiet()
                 eng.write_buffers(buf)          # back to the uploaded state, mailboxes released
             transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream(),
                                             ordered=a.exchange != "sync")

@@ -201,6 +201,13 @@ class Engine:
         self._check(load_library().sb_get_info(self._h, key.encode(), ctypes.byref(v)))
         return v.value
 
+    def sync_quiet(self):
+        """sync() that swallows a reported device-side timeout (used when abandoning a failed exchange set-up)."""
+        try:
+            self.sync()
+        except EngineError:
+            pass
+
     def halo_configure(self, ghost_particles, send_particles, ghost_beams=(), send_beams=()):
         a = [np.ascontiguousarray(x, dtype="<u4") for x in (ghost_particles, send_particles, ghost_beams, send_beams)]
         self._check(load_library().sb_halo_configure(self._h, _ptr(a[0]), a[0].size, _ptr(a[1]), a[1].size,

@@ -296,6 +296,33 @@ class TorchTransport:
         self.exchanges += 1
 
 
+def ghost_mismatches(plan, buf, dist, torch, device):
+    """Right after a refresh every ghost record must equal its owner's current record.  `buf` is this rank's
+    state read back from the engine; the owners' records travel over torch.distributed (tensors on `device`:
+    cuda for nccl, cpu for gloo), independently of the transport being checked.  Returns how many ghost
+    records differ (bitwise) on this rank."""
+    ops, pending = [], []
+    for p in plan.peers:
+        mine = np.concatenate([buf.particles[p.send_p].reshape(-1),
+                               buf.beams["target_length"][p.send_b], buf.beams["last_length"][p.send_b]]).astype("<f4")
+        t_send = torch.from_numpy(mine.view("<i4").copy()).to(device)
+        t_recv = torch.empty(6 * p.ghost_p.size + 2 * p.ghost_b.size, dtype=torch.int32, device=device)
+        ops += [dist.P2POp(dist.isend, t_send, p.rank), dist.P2POp(dist.irecv, t_recv, p.rank)]
+        pending.append((p, t_recv, t_send))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    bad = 0
+    for p, t_recv, _ in pending:
+        theirs = t_recv.cpu().numpy().view("<u4")
+        n = p.ghost_p.size
+        have = np.concatenate([buf.particles[p.ghost_p].reshape(-1), buf.beams["target_length"][p.ghost_b],
+                               buf.beams["last_length"][p.ghost_b]]).astype("<f4").view("<u4")
+        diff = theirs != have
+        bad += int(diff[:6 * n].reshape(-1, 6).any(axis=1).sum()) + int(diff[6 * n:].reshape(2, -1).any(axis=0).sum())
+    return bad
+
+
 def gather_owned(plan, buf):
     """(global particle ids, particle rows, global beam keys, beam records) of what this rank owns."""
     op, ob = plan.owned_particles, plan.owned_beams

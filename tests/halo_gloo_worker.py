@@ -26,6 +26,12 @@ def main():
     ex = halo.Exchanger(eng, plan, CpuTorchTransport(torch, dist))
     ex.step(steps)
     out = eng.load(buf)
+    # 42 = 10 refresh periods + 2 substeps: ghosts are stale by two substeps now, so the cross-check must see it;
+    # two more substeps complete a period and it must come back clean
+    stale = halo.ghost_mismatches(plan, out, dist, torch, torch.device("cpu"))
+    ex.step(2)
+    fresh = halo.ghost_mismatches(plan, eng.load(buf), dist, torch, torch.device("cpu"))
+    assert stale > 0 and fresh == 0, (stale, fresh)
     gid, prt, bkey, brec = halo.gather_owned(plan, out)
     gathered = [None] * world
     dist.all_gather_object(gathered, (gid, prt, bkey, brec.tobytes()))
