@@ -52,7 +52,8 @@ typedef enum sb_status {
 /* particle-particle collision broad phase (compute.wgsl:142-170) */
 #define SB_COLLIDE_OFF 0      /* skip the collision loop (BASELINE config 2) */
 #define SB_COLLIDE_ALLPAIRS 1 /* the reference's O(P^2) scan, LDS-tiled */
-#define SB_COLLIDE_GRID 2     /* spatial hash; same pair set and summation order => same bits */
+#define SB_COLLIDE_GRID 2     /* spatial hash + neighbour lists; same pair set and summation order => same bits
+                               * as SB_COLLIDE_ALLPAIRS.  The default (sb_default_options). */
 
 /* device schedule of one substep */
 #define SB_PATH_AUTO 0

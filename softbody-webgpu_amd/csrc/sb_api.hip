@@ -112,7 +112,7 @@ void sb_default_options(sb_options *o)
     o->max_particles = 65536;   // engineMapping.ts:362
     o->max_beams = 65536;       // engineMapping.ts:363
     o->layout = SB_LAYOUT_V1;
-    o->collision_mode = SB_COLLIDE_ALLPAIRS;
+    o->collision_mode = SB_COLLIDE_GRID; // the bits of the reference's all-pairs scan (compute.wgsl:142-170), not its O(P^2) cost
     o->path = SB_PATH_AUTO;
     o->device_ordinal = 0;
 }

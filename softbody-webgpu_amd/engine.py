@@ -117,7 +117,7 @@ class Engine:
     (writeBuffers / loadBuffers / frame) and the C ABI."""
 
     def __init__(self, bounds_size=1000.0, particle_radius=10.0, subticks=64, layout=LAYOUT_V1,
-                 max_particles=65536, max_beams=65536, collision_mode=COLLIDE_ALLPAIRS,
+                 max_particles=65536, max_beams=65536, collision_mode=COLLIDE_GRID,
                  path=PATH_AUTO, tile_particles=0, device=0, grid_skin=0.0):
         L = load_library()
         o = SbOptions()

@@ -40,7 +40,7 @@ class WGPUSoftbodyEngineWorker {
         this.handle = this.addon.create({
             boundsSize: this.boundsSize, particleRadius: this.particleRadius, subticks: this.subticks,
             maxParticles: this.bufferMapper.maxParticles, maxBeams: this.bufferMapper.maxBeams, layout: this.layout,
-            collisionMode: o.collisionMode !== undefined ? o.collisionMode : COLLIDE.ALLPAIRS,
+            collisionMode: o.collisionMode !== undefined ? o.collisionMode : COLLIDE.GRID, // same bits as ALLPAIRS
             path: o.path !== undefined ? o.path : PATH.AUTO, tileParticles: o.tileParticles || 0, device: o.device || 0
         });
         this.running = true;

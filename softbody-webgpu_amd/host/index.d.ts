@@ -146,7 +146,7 @@ export type NativeEngineOptions = Partial<WGPUSoftbodyEngineOptions> & {
     readonly maxParticles?: number
     readonly maxBeams?: number
     readonly maxByteLength?: number
-    readonly collisionMode?: 0 | 1 | 2  // COLLIDE.OFF | ALLPAIRS | GRID
+    readonly collisionMode?: 0 | 1 | 2  // COLLIDE.OFF | ALLPAIRS | GRID (default GRID: the bits of ALLPAIRS)
     readonly path?: 0 | 1 | 2           // PATH.AUTO | ATOMIC | TILED
     readonly tileParticles?: number
     readonly device?: number

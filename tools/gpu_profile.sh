@@ -17,6 +17,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || { echo pmc write failed; tail -5 $OUT/pmc_write.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- $OLDPWD/tools/hbm_calib > $OUT/calib_fetch.log 2>&1 || { echo calib fetch failed; tail -5 $OUT/calib_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calib_write -- $OLDPWD/tools/hbm_calib > $OUT/calib_write.log 2>&1 || { echo calib write failed; tail -5 $OUT/calib_write.log; exit 1; }
+# where the dominant kernel's time goes: SQ counters, two passes of eight (own runs: --pmc with --kernel-trace only)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- $BENCH > $OUT/pmc_sq1.log 2>&1 || echo "pmc sq1 failed"
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $BENCH > $OUT/pmc_sq2.log 2>&1 || echo "pmc sq2 failed"
 # config 3 (grid collisions): bench line + kernel trace
 python3 $OLDPWD/bench.py --collisions grid --no-cpu-baseline > $OUT/bench_grid.json 2> $OUT/bench_grid.err || { echo grid bench failed; tail -5 $OUT/bench_grid.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grid -- python3 $OLDPWD/bench.py --collisions grid --steps 200 --warmup 16 --no-cpu-baseline > $OUT/trace_grid.log 2>&1 || { echo grid trace failed; exit 1; }

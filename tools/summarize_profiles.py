@@ -83,5 +83,11 @@ for which, ctr, corr in (("pmc_fetch", "FETCH_SIZE", f_corr), ("pmc_write", "WRI
 for name, t in traffic.items():
     t["hbm_bytes_per_launch"] = sum(x["bytes"] for x in t.values() if isinstance(x, dict))
 summary["traffic"] = traffic
+sq = {}
+for which in ("pmc_sq1", "pmc_sq2"):
+    for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
+        if k.startswith("void k_substep_tiled"):
+            sq.setdefault(k.split("(")[0].replace("void ", ""), {})[c] = {"launches": n, "per_launch": avg}
+summary["sq_counters"] = sq
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps({k: summary[k] for k in ("kernel_stats", "traffic", "fetch_correction", "write_correction") if k in summary}, indent=1))
