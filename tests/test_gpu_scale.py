@@ -55,6 +55,32 @@ def test_config2_schedule_and_collision_mode_independence(sb, scene):
     assert not np.array_equal(p, scene.particles)
 
 
+def test_config3_contacts_bit_exact_vs_oracle(sb, oracle):
+    """Config 3 at full size WITH contacts: the same 1 M-particle lattice packed at 19.5 < 2r = 20, so every
+    particle starts in contact with its four neighbours (eight within list reach) and the blob bursts
+    apart: neighbour lists in use everywhere, hash + lists rebuilt several times.  Bit-exact against the
+    oracle's grid mode (itself bit-identical to all-pairs, tests/test_oracle_kat.py)."""
+    n = 10
+    buf = sb.scenes.lattice_buffers(W, H, d=19.5, origin=(1000.0, 1000.0), jitter=0.2, layout=2)
+    ref = oracle.OracleEngine(BOUNDS, 10.0, 64, 2, oracle.COLLIDE_GRID, threads=16)
+    ref.write_buffers(buf)
+    ref.step(n)
+    exp = ref.load_buffers(buf.copy())
+    assert np.isfinite(exp.particles).all()
+    eng = sb.Engine(bounds_size=BOUNDS, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                    collision_mode=2, path=2)
+    eng.write_buffers(buf)
+    eng.step(n)
+    got = eng.load_buffers(buf.copy())
+    builds = eng.info("grid_builds")
+    eng.destroy()
+    assert builds >= 2
+    assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4"))
+    assert got.beams.tobytes() == exp.beams.tobytes()
+    off, _ = gpu_run(sb, buf, n, collision_mode=0, path=2)
+    assert (off.particles != got.particles).any(axis=1).mean() > 0.9   # the contacts really acted
+
+
 def test_momentum_drift_without_external_forces(sb, scene):
     """Beam forces are equal and opposite in fixed point (compute.wgsl:127-130), so with gravity, drag
     and walls out of the picture total momentum only moves by per-particle float rounding."""
