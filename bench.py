@@ -32,6 +32,11 @@ def parse():
     ap.add_argument("--width", type=int, default=1000, help="lattice columns per GPU")
     ap.add_argument("--height", type=int, default=1000, help="lattice rows")
     ap.add_argument("--collisions", choices=["off", "grid"], default="off")
+    ap.add_argument("--spacing", type=float, default=30.0, help="lattice spacing d (particle radius is 10)")
+    ap.add_argument("--origin-y", type=float, default=1000.0, help="y of the lattice's bottom row (10 = resting on the floor)")
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE config 3 with its contacts ACTIVE: 4000x250 lattice at spacing 22 resting on the floor "
+                         "(weight closes the lower rows to < 2r: self-collision + floor boundary), spatial-hash collisions")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ghost-depth", type=int, default=24,
@@ -194,17 +199,19 @@ def main():
     from importlib import import_module
     halo = import_module("softbody_webgpu_amd.halo") if world > 1 else None
 
+    if a.config3:
+        a.width, a.height, a.spacing, a.origin_y, a.collisions = 4000, 250, 22.0, 10.0, "grid"
     W, H = a.width, a.height
-    d = 30.0
+    d = a.spacing
     mode = {"off": 0, "grid": 2}[a.collisions]
     path = {"auto": 0, "atomic": 1, "tiled": 2}[a.path]
     # global scene: N slabs of W columns side by side (weak scaling: per-GPU work is fixed)
     bounds = float(max(W * world, H) * d + 2000.0)
     if world == 1:
-        buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0, layout=2)
+        buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0, layout=2)
         plan = None
     else:
-        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, 1000.0), jitter=1.0,
+        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0,
                                     depth=a.ghost_depth)
     if a.mixed_stiffness:
         if plan is not None:
@@ -263,10 +270,13 @@ def main():
         P_total = P_local
 
     if rank == 0:
-        workload = ("BASELINE config 2: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
-                    "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout"
-                    % (W, H, P_local, B_local, "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else
-                       "spring 50 damp 700", a.subticks, a.collisions))
+        workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
+                    "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
+                    % ("3" if a.config3 else "2", W, H, P_local, B_local,
+                       "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else "spring 50 damp 700", a.subticks,
+                       a.collisions, "" if (d == 30.0 and a.origin_y == 1000.0) else
+                       ", spacing %g, bottom row at y=%g%s" % (d, a.origin_y, " (resting on the floor, lower rows in contact)"
+                                                               if a.config3 else "")))
         copies = eng.info("beam_copies")
         alg_bytes = 52.0 * B_local + 48.0 * P_local  # per substep, one launch
         roof = None
