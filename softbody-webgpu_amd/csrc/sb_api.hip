@@ -498,7 +498,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.nl = e->d_nl;
         e->grid.nl_stride = P;
         const float reach = e->prm.particle_radius * 2.0f + 2.0f * skin;
-        e->nl_reach2 = reach * reach * 1.001f;
+        e->grid.nl_reach2 = reach * reach * 1.001f;
+        e->grid.fresh = &e->d_grid_ctl[0].rebuild;
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     if (e->path == SB_PATH_ATOMIC) {

@@ -86,8 +86,11 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
             }
         }
     }
-    if (MODE == SB_COLLIDE_GRID && active)
-        sb_collide_list(grid, grid.nl_count[i], prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
+    if (MODE == SB_COLLIDE_GRID && active) {
+        const bool fresh = SB_AGENT_LOAD(grid.fresh) != 0u;
+        const uint32_t count = fresh ? sb_neighbour_list_build(grid, i, self.p) : grid.nl_count[i];
+        sb_collide_list(grid, count, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
+    }
     float moved = 0.0f;
     if (active) {
         int2 f = forces[i];
@@ -124,14 +127,19 @@ SB_DEV uint32_t sb_tile_of_block(uint32_t b, uint32_t n)
 // HBM traffic per substep = beam slice (36 B read + 16 B written per copy) + particles
 // (24 B read + 24 B written) + halo positions (8 B each, mostly L2 hits): the force
 // accumulator (compute.wgsl:68-69) never leaves the CU.
+#define SB_TILED_PARAMS                                                                                             \
+    SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,                   \
+        const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,                                 \
+        const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits, \
+        const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts c, SbParams prm, uint32_t *broken,         \
+        const uint32_t *__restrict__ pidx, SbGrid grid, uint32_t *blk_max, const uint32_t *__restrict__ acc_flag_r, \
+        uint32_t *acc_flag_w
+#define SB_TILED_ARGS                                                                                               \
+    r, w, b, tile_p0, tile_b0, tile_h0, halo_idx, ntiles, cap_all, cap_own, lbits, mat_tab, nmat, c, prm, broken,   \
+        pidx, grid, blk_max, acc_flag_r, acc_flag_w
+
 template <int MODE, int MAT, bool AUX>
-__global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
-    SbParticleArrays r, SbParticleArrays w, SbBeamArrays b, const uint32_t *__restrict__ tile_p0,
-    const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,
-    const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits,
-    const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts c, SbParams prm,
-    uint32_t *broken, const uint32_t *__restrict__ pidx, SbGrid grid, uint32_t *blk_max,
-    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
+__device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     float2 *s_pos = (float2 *)sb_lds;
@@ -196,12 +204,15 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
     if (MAT != 0)
         for (uint32_t i = tid; i < nmat * SB_MAT_ROW; i += SB_TILE_BLOCK) s_mat[i] = mat_tab[i];
     // SB_COLLIDE_GRID: the length of each particle's neighbour list is fetched here, long before phase 2 walks it
+    // (on the substep right after a hash build the lists do not exist yet: phase 2 makes them)
     uint32_t ncand[SB_UNROLL];
+    bool fresh = false;
     if (MODE == SB_COLLIDE_GRID) {
+        fresh = SB_AGENT_LOAD(grid.fresh) != 0u;
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
             const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
-            ncand[u] = i < n_own ? grid.nl_count[p0 + i] : 0u;
+            ncand[u] = (i < n_own && !fresh) ? grid.nl_count[p0 + i] : 0u;
         }
     }
     __syncthreads();
@@ -309,6 +320,7 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
         const float2 p_old = particle.p;
         if (MODE == SB_COLLIDE_GRID) {
             const SbParticle self = particle; // :141
+            if (fresh) count = sb_neighbour_list_build(grid, g, self.p);
 #if !(SB_ABLATE & 64) // diagnostic build: no collision scan
             sb_collide_list(grid, count, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx,
                             r.pos, r.vel);
@@ -335,13 +347,28 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(
     }
     for (uint32_t i = tid + SB_UNROLL * SB_TILE_BLOCK; i < n_own; i += SB_TILE_BLOCK) {
         finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f),
-               MODE == SB_COLLIDE_GRID ? grid.nl_count[p0 + i] : 0u);
+               (MODE == SB_COLLIDE_GRID && !fresh) ? grid.nl_count[p0 + i] : 0u);
     }
 #if !(SB_ABLATE & 128) // diagnostic build: no displacement tracking
     if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
 #endif
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
     if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
+}
+
+// The two entry points.  With the collision walk compiled in, the body wants 71 VGPRs: 7 waves per SIMD, i.e.
+// three 8-wave workgroups per CU and 768 resident slots for ~1000 tiles (a second, mostly empty round).  Capping
+// it at 64 VGPRs (a few spilled lanes) keeps four workgroups per CU; the collision-free variants (50-58 VGPRs)
+// are left alone.
+template <int MAT, bool AUX>
+__global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(SB_TILED_PARAMS)
+{
+    sb_substep_tiled<SB_COLLIDE_OFF, MAT, AUX>(SB_TILED_ARGS);
+}
+template <int MAT, bool AUX>
+__global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_substep_tiled_grid(SB_TILED_PARAMS)
+{
+    sb_substep_tiled<SB_COLLIDE_GRID, MAT, AUX>(SB_TILED_ARGS);
 }
 
 // ---------------------------------------------------------------- spatial hash build
@@ -388,8 +415,6 @@ struct SbGridBuild {
     float4 *rec;
     uint32_t ncell1, nchunks;
     uint32_t *bar, *err;
-    uint32_t *nl_count, *nl;
-    float list_reach2;
 };
 
 __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const uint32_t *blk_max, uint32_t nblk,
@@ -426,7 +451,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     if (!rebuild) return;
 
     const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
-    const uint32_t bar0 = builds * 4u * gridDim.x; // arrivals before this build (four barriers per build)
+    const uint32_t bar0 = builds * 3u * gridDim.x; // arrivals before this build (three barriers per build)
     // ---- counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
     // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
     // (four particles per thread and round, so that four returning atomics are in flight per lane)
@@ -531,9 +556,6 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         }
     }
     for (uint32_t c = gtid; c < w.ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
-    sb_grid_barrier(w.bar, bar0 + 4u * gridDim.x, w.err);
-    // ---- neighbour lists from the fresh hash: what the particle kernels walk until the next build
-    for (uint32_t i = gtid; i < P; i += nthreads) sb_neighbour_list_build(g, w.nl_count, w.nl, i, pos[i], w.list_reach2);
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -695,10 +717,11 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
         }();
         const uint32_t blocks = std::min(std::max(work, 1u), max_blocks);
         SbGridBuild gb{e->d_cell_cnt, e->d_cell_scan, e->d_block_off, e->d_rank, e->d_cell_of, e->d_cell_start,
-                       e->d_rec, n, nchunks, e->d_grid_bar, e->dev_err, e->d_nl_count, e->d_nl, e->nl_reach2};
+                       e->d_rec, n, nchunks, e->d_grid_bar, e->dev_err};
         k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
                                                             r.pos, e->d_pslot, e->P, e->grid, gb);
         e->grid_par ^= 1u;
+        e->grid.fresh = &e->d_grid_ctl[e->grid_par].rebuild; // what that launch just published
     }
     uint32_t *blk_out = e->d_blk_max[e->grid_par]; // the slots the NEXT maintain launch reads
     if (e->path == SB_PATH_ATOMIC) {
@@ -714,14 +737,14 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #undef SB_LAUNCH_P
         }
     } else if (e->ntiles) {
-#define SB_LAUNCH_T(M, T, A) k_substep_tiled<M, T, A><<<e->ntiles, SB_TILE_BLOCK, e->lds_bytes, e->stream>>>(            \
+#define SB_LAUNCH_T(K, T, A) K<T, A><<<e->ntiles, SB_TILE_BLOCK, e->lds_bytes, e->stream>>>(                            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
         e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
         blk_out, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
-#define SB_LAUNCH_TA(M, T) do { if (write_aux) SB_LAUNCH_T(M, T, true); else SB_LAUNCH_T(M, T, false); } while (0)
-#define SB_LAUNCH_TM(M) do { if (e->mat_mode == 2) SB_LAUNCH_TA(M, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(M, 1); else SB_LAUNCH_TA(M, 0); } while (0)
-        if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(SB_COLLIDE_GRID);
-        else SB_LAUNCH_TM(SB_COLLIDE_OFF);
+#define SB_LAUNCH_TA(K, T) do { if (write_aux) SB_LAUNCH_T(K, T, true); else SB_LAUNCH_T(K, T, false); } while (0)
+#define SB_LAUNCH_TM(K) do { if (e->mat_mode == 2) SB_LAUNCH_TA(K, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(K, 1); else SB_LAUNCH_TA(K, 0); } while (0)
+        if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(k_substep_tiled_grid);
+        else SB_LAUNCH_TM(k_substep_tiled);
 #undef SB_LAUNCH_TM
 #undef SB_LAUNCH_TA
 #undef SB_LAUNCH_T

@@ -244,11 +244,16 @@ struct SbGrid {
     const uint32_t *cell_of;    // per particle: its cell at the last build
     float x0, y0, cell, skin;
     uint32_t nx, ny;
-    // neighbour lists, made at build time (sb_neighbour_list_build): per particle the internal indices of
-    // everybody within 2r + 2*skin, in ascending slot order; entry k of particle i at nl[k * nl_stride + i]
-    const uint32_t *nl_count;   // entries, or SB_NL_OVERFLOW: more than SB_NL_CAP, scan the cells instead
-    const uint32_t *nl;
+    // neighbour lists (sb_neighbour_list_build): per particle the internal indices of everybody within
+    // 2r + 2*skin at build time, in ascending slot order; entry k of particle i at nl[k * nl_stride + i].
+    // Written by the particle kernel of the substep that follows a hash build (*fresh != 0: every particle
+    // makes its own list from the fresh hash, with the whole chip's parallelism, and uses it at once), read by
+    // the same thread on the substeps after it.
+    uint32_t *nl_count;         // entries, or SB_NL_OVERFLOW: more than SB_NL_CAP, scan the cells instead
+    uint32_t *nl;
     uint32_t nl_stride;
+    float nl_reach2;            // (2r + 2*skin)^2 with a rounding margin
+    const uint32_t *fresh;      // SbGridCtl::rebuild of the k_grid_maintain launch just before this kernel
 };
 #define SB_NL_CAP 16u
 #define SB_NL_OVERFLOW 0xFFFFFFFFu
@@ -373,13 +378,13 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbPar
     }
 }
 
-// Build time (positions in the records are current): everybody within `reach` = 2r + 2*skin of particle i,
+// On the substep of a hash build (positions in the records are the READ state): everybody within 2r + 2*skin of particle i,
 // in ascending slot order (repeated selection of the smallest slot above the last one taken, as above).
 // While the displacement bound D <= skin, a pair closer than 2r NOW was closer than 2r + 2D at build time,
 // so the list is a superset of i's contacts until the next build.  NaN distances are kept (conservative).
-SB_DEV void sb_neighbour_list_build(const SbGrid &g, uint32_t *nl_count, uint32_t *nl, uint32_t i, float2 p,
-                                    float reach2)
+SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, uint32_t i, float2 p)
 {
+    const float reach2 = g.nl_reach2;
     const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
     uint32_t n = 0u, last = 0u;
     bool have_last = false;
@@ -402,12 +407,13 @@ SB_DEV void sb_neighbour_list_build(const SbGrid &g, uint32_t *nl_count, uint32_
             n = SB_NL_OVERFLOW;
             break;
         }
-        nl[n * g.nl_stride + i] = best_id;
+        g.nl[n * g.nl_stride + i] = best_id;
         n++;
         last = best_slot;
         have_last = true;
     }
-    nl_count[i] = n;
+    g.nl_count[i] = n;
+    return n;
 }
 
 // The collision loop of compute.wgsl:144-170 over particle i's neighbour list (`count` = nl_count[i], fetched
