@@ -191,6 +191,29 @@ def test_grid_default_scene_equals_allpairs_oracle(sb, oracle, path):
     assert_same(got, exp, "grid default scene path %d" % path)
 
 
+def test_default_scene_long_run_default_options(sb, oracle):
+    """The reference's default scene for 90 frames (5760 substeps, 1.5 s of its wall clock at 60 fps) with the
+    engine's DEFAULT collision mode (spatial hash + neighbour lists, tiled path) against the oracle's all-pairs
+    scan: blobs land, pile up, yield and break beams, delete passes run; still bit for bit the same."""
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    eng = sb.Engine(layout=1, max_particles=buf.max_particles, max_beams=buf.max_beams)   # every option at its default
+    assert eng.info("path") == TILED
+    ref = oracle.OracleEngine(1000.0, 10.0, 64, 1, ALLPAIRS, threads=4)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    for frame in range(90):
+        eng.frame()
+        ref.frame()
+        if frame in (9, 44):
+            assert_same(eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy()), "frame %d" % frame)
+    got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+    builds = eng.info("grid_builds")
+    eng.destroy()
+    assert np.isfinite(exp.particles).all()
+    assert_same(got, exp, "default scene, 90 frames")
+    assert 1 < builds < 5760
+
+
 @pytest.mark.parametrize("path", [ATOMIC, TILED])
 def test_grid_particle_soup(sb, oracle, path):
     """2000 free particles at ~30 % area coverage with random velocities, one coincident pair and a
