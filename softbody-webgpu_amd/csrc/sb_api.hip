@@ -477,8 +477,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_TRY(dev_alloc(e, &e->d_grid_ctl, 2));
         const size_t nblk = std::max<size_t>(e->ntiles, (P + 255) / 256) + 1;
         for (int k = 0; k < 2; k++) {
-            SB_TRY(dev_alloc(e, &e->d_blk_max[k], nblk));
-            SB_HIP(e, hipMemset(e->d_blk_max[k], 0, nblk * 4));
+            SB_TRY(dev_alloc(e, &e->d_blk_max[k], 3 * nblk)); // max | sum dx | sum dy per workgroup
+            SB_HIP(e, hipMemset(e->d_blk_max[k], 0, 3 * nblk * 4));
         }
         SB_TRY(dev_alloc(e, &e->d_grid_bar, 1));
         SB_HIP(e, hipMemset(e->d_grid_bar, 0, 4));
@@ -499,7 +499,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.nl_stride = P;
         const float reach = e->prm.particle_radius * 2.0f + 2.0f * skin;
         e->grid.nl_reach2 = reach * reach * 1.001f;
-        e->grid.fresh = &e->d_grid_ctl[0].rebuild;
+        e->grid.ctl = &e->d_grid_ctl[0];
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     if (e->path == SB_PATH_ATOMIC) {

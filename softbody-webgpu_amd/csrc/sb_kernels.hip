@@ -8,6 +8,7 @@
 //                   with LDS integer atomics and consumed in the same launch.
 // Both are HBM-bandwidth-bound (no MFMA: < 1 flop/byte).
 #include <algorithm>
+#include <type_traits>
 
 #include "sb_engine.h"
 
@@ -87,16 +88,19 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         }
     }
     if (MODE == SB_COLLIDE_GRID && active) {
-        const bool fresh = SB_AGENT_LOAD(grid.fresh) != 0u;
-        const uint32_t count = fresh ? sb_neighbour_list_build(grid, i, self.p) : grid.nl_count[i];
-        sb_collide_list(grid, count, prm, c.friction, elasticity_coeff, particle, self, i, pidx, r.pos, r.vel);
+        sb_collide_slow(grid, SB_AGENT_LOAD(&grid.ctl->rebuild) != 0u, prm, c.friction, elasticity_coeff, particle, self, i,
+                        pidx, r.pos, r.vel);
     }
     float moved = 0.0f;
     if (active) {
         int2 f = forces[i];
         forces[i] = make_int2(0, 0); // atomicExchange(..., 0), :184-185
         sb_particle_finish(prm, c, particle, f.x, f.y);
-        moved = fmaxf(sb_abs(particle.p.x - self.p.x), sb_abs(particle.p.y - self.p.y)) * 1.4142137f;
+        if (MODE == SB_COLLIDE_GRID) {
+            const float dx = particle.p.x - self.p.x, dy = particle.p.y - self.p.y;
+            moved = fmaxf(sb_abs(dx - SB_AGENT_LOAD(&grid.ctl->cx)), sb_abs(dy - SB_AGENT_LOAD(&grid.ctl->cy))) * 1.4142137f;
+            if (threadIdx.x == 0) sb_store_sample_displacement(blk_max, gridDim.x, dx, dy);
+        }
     }
     if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
     if (!active) return;
@@ -207,8 +211,11 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
     // (on the substep right after a hash build the lists do not exist yet: phase 2 makes them)
     uint32_t ncand[SB_UNROLL];
     bool fresh = false;
+    float drift_x = 0.0f, drift_y = 0.0f; // SbGridCtl: the common displacement this substep is measured against
     if (MODE == SB_COLLIDE_GRID) {
-        fresh = SB_AGENT_LOAD(grid.fresh) != 0u;
+        fresh = SB_AGENT_LOAD(&grid.ctl->rebuild) != 0u;
+        drift_x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_AGENT_LOAD(&grid.ctl->cx)))); // uniform: SGPRs
+        drift_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_AGENT_LOAD(&grid.ctl->cy))));
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
             const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
@@ -311,7 +318,8 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
     // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
     bool any_acc = false;
     float moved = 0.0f;
-    auto finish = [&](uint32_t i, float2 vel, float2 acc, uint32_t count) {
+    // `slow` (compile-time at each call site): this particle takes sb_collide_slow instead of walking its list
+    auto finish = [&](uint32_t i, float2 vel, float2 acc, uint32_t count, auto slow) {
         const uint32_t g = p0 + i;
         SbParticle particle;
         particle.p = s_pos[i];
@@ -320,10 +328,10 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
         const float2 p_old = particle.p;
         if (MODE == SB_COLLIDE_GRID) {
             const SbParticle self = particle; // :141
-            if (fresh) count = sb_neighbour_list_build(grid, g, self.p);
 #if !(SB_ABLATE & 64) // diagnostic build: no collision scan
-            sb_collide_list(grid, count, prm, c.friction, sb_div(c.elasticity + 1.0f, 2.0f), particle, self, g, pidx,
-                            r.pos, r.vel);
+            const float ec = sb_div(c.elasticity + 1.0f, 2.0f); // :143
+            if (decltype(slow)::value) sb_collide_slow(grid, fresh, prm, c.friction, ec, particle, self, g, pidx, r.pos, r.vel);
+            else sb_collide_list(grid, count, prm, c.friction, ec, particle, self, g, pidx, r.pos, r.vel);
 #endif
         }
 #if SB_ABLATE & 2 // diagnostic build: particle arithmetic replaced by a data-dependent dummy
@@ -332,22 +340,43 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
 #else
         sb_particle_finish(prm, c, particle, s_f[2 * i], s_f[2 * i + 1]);
 #endif
-        if (MODE == SB_COLLIDE_GRID)
-            moved = fmaxf(moved, fmaxf(sb_abs(particle.p.x - p_old.x), sb_abs(particle.p.y - p_old.y)) * 1.4142137f);
+        if (MODE == SB_COLLIDE_GRID) {
+            const float dx = particle.p.x - p_old.x, dy = particle.p.y - p_old.y;
+            moved = fmaxf(moved, fmaxf(sb_abs(dx - drift_x), sb_abs(dy - drift_y)) * 1.4142137f);
+            if (i == 0u) sb_store_sample_displacement(blk_max, ntiles, dx, dy); // i == 0 is thread 0's first particle
+        }
         w.pos[g] = particle.p;
         w.vel[g] = particle.v;
         const bool nz = (__float_as_uint(particle.a.x) | __float_as_uint(particle.a.y)) != 0u; // -0.0 counts
         any_acc |= nz;
         if (nz || acc_w_dirty) w.acc[g] = particle.a;
     };
+    // main pass: every particle whose list can simply be walked (all of them, on almost every substep)
+    bool any_slow = false;
+    if (!fresh) {
 #pragma unroll
-    for (int u = 0; u < SB_UNROLL; u++) {
-        const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
-        if (i < n_own) finish(i, pv[u], pa[u], MODE == SB_COLLIDE_GRID ? ncand[u] : 0u);
+        for (int u = 0; u < SB_UNROLL; u++) {
+            const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
+            if (i < n_own) {
+                const uint32_t count = MODE == SB_COLLIDE_GRID ? ncand[u] : 0u;
+                if (MODE == SB_COLLIDE_GRID && count == SB_NL_OVERFLOW) any_slow = true;
+                else finish(i, pv[u], pa[u], count, std::false_type{});
+            }
+        }
+        for (uint32_t i = tid + SB_UNROLL * SB_TILE_BLOCK; i < n_own; i += SB_TILE_BLOCK) {
+            const uint32_t count = MODE == SB_COLLIDE_GRID ? grid.nl_count[p0 + i] : 0u;
+            if (MODE == SB_COLLIDE_GRID && count == SB_NL_OVERFLOW) any_slow = true;
+            else finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f), count, std::false_type{});
+        }
     }
-    for (uint32_t i = tid + SB_UNROLL * SB_TILE_BLOCK; i < n_own; i += SB_TILE_BLOCK) {
-        finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f),
-               (MODE == SB_COLLIDE_GRID && !fresh) ? grid.nl_count[p0 + i] : 0u);
+    // second pass, SB_COLLIDE_GRID only: the substep after a hash build (every particle makes its list), or the
+    // particles of piles that overflow their lists
+    if (MODE == SB_COLLIDE_GRID && (fresh || __syncthreads_or(any_slow ? 1 : 0))) {
+#pragma unroll 1
+        for (uint32_t i = tid; i < n_own; i += SB_TILE_BLOCK) {
+            if (!fresh && grid.nl_count[p0 + i] != SB_NL_OVERFLOW) continue;
+            finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f), 0u, std::true_type{});
+        }
     }
 #if !(SB_ABLATE & 128) // diagnostic build: no displacement tracking
     if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
@@ -366,7 +395,10 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(SB_TILED_PARAMS
     sb_substep_tiled<SB_COLLIDE_OFF, MAT, AUX>(SB_TILED_ARGS);
 }
 template <int MAT, bool AUX>
-__global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_substep_tiled_grid(SB_TILED_PARAMS)
+#ifndef SB_GRID_WAVES
+#define SB_GRID_WAVES 8
+#endif
+__global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(SB_GRID_WAVES, 8))) void k_substep_tiled_grid(SB_TILED_PARAMS)
 {
     sb_substep_tiled<SB_COLLIDE_GRID, MAT, AUX>(SB_TILED_ARGS);
 }
@@ -422,7 +454,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
                                                             const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
                                                             SbGridBuild w)
 {
-    __shared__ float s_wave_max[SB_MT / 64];
+    __shared__ float s_wave_max[SB_MT / 64], s_wave_sx[SB_MT / 64], s_wave_sy[SB_MT / 64];
     __shared__ uint32_t s_wave[SB_MT / 64];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x;
@@ -430,16 +462,37 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     const SbGridCtl *cin = ctl + par;
     const float skin = SB_AGENT_LOAD(&cin->skin), accum_in = SB_AGENT_LOAD(&cin->accum); // in flight with the slots
     const uint32_t builds = SB_AGENT_LOAD(&cin->builds), force = SB_AGENT_LOAD(&cin->force);
-    float m = 0.0f;
-    for (uint32_t i = tid; i < nblk; i += SB_MT) m = fmaxf(m, __uint_as_float(blk_max[i])); // per-lane addresses: vector loads
+    const float c_used_x = SB_AGENT_LOAD(&cin->cx), c_used_y = SB_AGENT_LOAD(&cin->cy); // what the last substep used
+    const float C_in_x = SB_AGENT_LOAD(&cin->Cx), C_in_y = SB_AGENT_LOAD(&cin->Cy);
+    float m = 0.0f, sx = 0.0f, sy = 0.0f;
+    for (uint32_t i = tid; i < nblk; i += SB_MT) { // per-lane addresses: vector loads
+        m = fmaxf(m, __uint_as_float(blk_max[i]));
+        sx += __uint_as_float(blk_max[nblk + i]);
+        sy += __uint_as_float(blk_max[2u * nblk + i]);
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((tid & 63u) == 0u) s_wave_max[tid >> 6] = m;
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off, 64));
+        sx += __shfl_xor(sx, off, 64);
+        sy += __shfl_xor(sy, off, 64);
+    }
+    if ((tid & 63u) == 0u) {
+        s_wave_max[tid >> 6] = m;
+        s_wave_sx[tid >> 6] = sx;
+        s_wave_sy[tid >> 6] = sy;
+    }
     __syncthreads();
-    float step = 0.0f;
-    for (int k = 0; k < SB_MT / 64; k++) step = fmaxf(step, s_wave_max[k]);
+    float step = 0.0f, tot_x = 0.0f, tot_y = 0.0f;
+    for (int k = 0; k < SB_MT / 64; k++) {
+        step = fmaxf(step, s_wave_max[k]);
+        tot_x += s_wave_sx[k];
+        tot_y += s_wave_sy[k];
+    }
     const float accum = accum_in + step; // bound for the READ state of this substep
     const bool rebuild = force != 0u || !(accum <= skin); // NaN-safe
+    // the common displacement the coming substep is measured against: the mean of the one just done
+    float mean_x = tot_x / (float)nblk, mean_y = tot_y / (float)nblk; // one sample particle per workgroup
+    if (!(sb_abs(mean_x) < 1.0e30f) || !(sb_abs(mean_y) < 1.0e30f)) mean_x = mean_y = 0.0f;
     if (blockIdx.x == 0 && tid == 0) {
         SbGridCtl *cout = ctl + (par ^ 1u);
         SB_AGENT_STORE(&cout->rebuild, rebuild ? 1u : 0u);
@@ -447,6 +500,10 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         SB_AGENT_STORE(&cout->accum, rebuild ? 0.0f : accum);
         SB_AGENT_STORE(&cout->skin, skin);
         SB_AGENT_STORE(&cout->builds, builds + (rebuild ? 1u : 0u));
+        SB_AGENT_STORE(&cout->cx, mean_x);
+        SB_AGENT_STORE(&cout->cy, mean_y);
+        SB_AGENT_STORE(&cout->Cx, rebuild ? 0.0f : C_in_x + c_used_x);
+        SB_AGENT_STORE(&cout->Cy, rebuild ? 0.0f : C_in_y + c_used_y);
     }
     if (!rebuild) return;
 
@@ -721,7 +778,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
         k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
                                                             r.pos, e->d_pslot, e->P, e->grid, gb);
         e->grid_par ^= 1u;
-        e->grid.fresh = &e->d_grid_ctl[e->grid_par].rebuild; // what that launch just published
+        e->grid.ctl = &e->d_grid_ctl[e->grid_par]; // what that launch just published
     }
     uint32_t *blk_out = e->d_blk_max[e->grid_par]; // the slots the NEXT maintain launch reads
     if (e->path == SB_PATH_ATOMIC) {

@@ -253,35 +253,42 @@ struct SbGrid {
     uint32_t *nl;
     uint32_t nl_stride;
     float nl_reach2;            // (2r + 2*skin)^2 with a rounding margin
-    const uint32_t *fresh;      // SbGridCtl::rebuild of the k_grid_maintain launch just before this kernel
+    const struct SbGridCtl *ctl; // what the k_grid_maintain launch just before this kernel published
 };
 #define SB_NL_CAP 16u
 #define SB_NL_OVERFLOW 0xFFFFFFFFu
 // The hash is rebuilt only when needed.  Cells are 2r*(1+1/64) + 2*skin wide; the engine keeps a bound
-// D on how far any particle can have moved since the last build (the sum of the per-substep maximum
-// displacements) and rebuilds before a substep whose READ state has D > skin.  While D <= skin, two
+// D on how far any particle can have moved since the last build RELATIVE TO THE COMMON DRIFT C of the scene,
+// and rebuilds before a substep whose READ state has D > skin.  Per substep every particle's displacement
+// d_i is measured against one vector c chosen beforehand (the mean displacement of the substep before: a
+// falling or sliding body moves almost rigidly, and a translation changes no distance); D accumulates
+// max_i |d_i - c| and C accumulates c.  Any choice of c keeps the bound valid: for a pair (i, j) the
+// relative motion since the build is sum (d_i - c) - sum (d_j - c), at most 2D.  So while D <= skin, two
 // particles closer than 2r NOW were closer than 2r + 2*skin AT BUILD TIME and sit in the same or
 // adjacent cells of the stale binning (still a superset of the contacts), and a candidate whose
-// build-time position is farther than 2r + skin from the querying particle's current position
-// cannot be in contact: candidates are found in the stale cells, pre-filtered on their stale
-// positions and tested exactly at their CURRENT positions.
+// build-time position, carried along by C, is farther than 2r + skin from the querying particle's
+// current position cannot be in contact: candidates are found in the stale cells, pre-filtered on
+// their drifted stale positions and tested exactly at their CURRENT positions.
 struct SbGridCtl {
-    uint32_t rebuild; // 1: the last k_grid_maintain launch rebuilt the hash (informational)
+    uint32_t rebuild; // 1: the k_grid_maintain launch that wrote this rebuilt the hash (the particle kernel
+                      //    that follows makes the neighbour lists)
     uint32_t force;   // set by the host (upload, halo unpack): rebuild unconditionally
     float accum;      // D for the READ state of the coming substep
     float skin;
     uint32_t builds;  // statistics
+    float cx, cy;     // c for the coming substep
+    float Cx, Cy;     // C for the READ state of the coming substep
 };
 #define SB_SCAN_BLOCK 2048u
 #define SB_MAX_WAVES 16
 #define SB_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SB_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// End of the particle kernel, called by EVERY thread of the block: this block's largest displacement
-// goes to blk_max[blockIdx.x] (float bits; anything not provably small, NaN included, reads as huge).
-// One plain slot per workgroup: funnelling ~1000 workgroups through atomics on one address cost
-// ~50 us per launch (same-address atomics retire one per ~12 ns).  k_grid_maintain reduces the slots.
-SB_DEV void sb_store_block_displacement(uint32_t *blk_max, float m)
+// End of the particle kernel, called by EVERY thread of the block: this block's largest drift-relative
+// displacement goes to blk[blockIdx.x] (float bits; anything not provably small reads as huge).  One plain slot
+// per workgroup: funnelling ~1000 workgroups through atomics on one address cost ~50 us per launch
+// (same-address atomics retire one per ~12 ns).  k_grid_maintain reduces the slots.
+SB_DEV void sb_store_block_displacement(uint32_t *blk, float m)
 {
     __shared__ float s_wave_max[SB_MAX_WAVES];
     m = (m < 1.0e30f) ? m : 1.0e30f;
@@ -292,8 +299,16 @@ SB_DEV void sb_store_block_displacement(uint32_t *blk_max, float m)
     if (threadIdx.x == 0) {
         float b = 0.0f;
         for (uint32_t w = 0; w < (blockDim.x >> 6); w++) b = fmaxf(b, s_wave_max[w]);
-        SB_AGENT_STORE(&blk_max[blockIdx.x], __float_as_uint(b));
+        SB_AGENT_STORE(&blk[blockIdx.x], __float_as_uint(b));
     }
+}
+
+// The scene's common drift is estimated from a SAMPLE: the first particle of every workgroup reports its
+// displacement (blk[nblk + blockIdx.x], blk[2*nblk + blockIdx.x]); any estimate keeps the bound valid.
+SB_DEV void sb_store_sample_displacement(uint32_t *blk, uint32_t nblk, float dx, float dy)
+{
+    SB_AGENT_STORE(&blk[nblk + blockIdx.x], __float_as_uint(sb_abs(dx) < 1.0e30f ? dx : 0.0f));
+    SB_AGENT_STORE(&blk[2u * nblk + blockIdx.x], __float_as_uint(sb_abs(dy) < 1.0e30f ? dy : 0.0f));
 }
 
 SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
@@ -337,6 +352,8 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbPar
     const float two_r = prm.particle_radius * 2.0f;
     const float far2 = two_r * two_r * 1.001f;
     const float reach = two_r + g.skin, stale_far2 = reach * reach * 1.001f;
+    // where this particle would be in the frame of the build: current position minus the common drift
+    const float qx = self.p.x - SB_AGENT_LOAD(&g.ctl->Cx), qy = self.p.y - SB_AGENT_LOAD(&g.ctl->Cy);
     bool have_last = false;
     uint32_t last = 0u;
     for (;;) {
@@ -354,8 +371,8 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbPar
                 for (int j = 0; j < 4; j++) {
                     const uint32_t slot = __float_as_uint(rc[j].z), id = __float_as_uint(rc[j].w);
                     if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
-                    const float sx = rc[j].x - self.p.x, sy = rc[j].y - self.p.y;
-                    if (sx * sx + sy * sy > stale_far2) continue; // cannot have come within 2r (see SbGrid)
+                    const float sx = rc[j].x - qx, sy = rc[j].y - qy;
+                    if (sx * sx + sy * sy > stale_far2) continue; // cannot have come within 2r (see SbGridCtl)
                     const float2 q = pos_r[id];
                     const float ex = q.x - self.p.x, ey = q.y - self.p.y;
                     const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
@@ -424,14 +441,9 @@ SB_DEV void sb_collide_list(const SbGrid &g, uint32_t count, const SbParams &prm
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
                             const float2 *__restrict__ vel_r)
 {
-    if (count == SB_NL_OVERFLOW) { // a pile denser than the list holds: scan the cells
-        const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
-        sb_collide_grid(g, rg, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
-        return;
-    }
     const float two_r = prm.particle_radius * 2.0f;
     const float far2 = two_r * two_r * 1.001f;
-    for (uint32_t k = 0; k < count; k++) {
+    for (uint32_t k = 0; k < count; k++) { // count is a real length here, never SB_NL_OVERFLOW
         const uint32_t id = g.nl[k * g.nl_stride + i];
         const float2 q = pos_r[id];
         const float ex = q.x - self.p.x, ey = q.y - self.p.y;
@@ -439,6 +451,23 @@ SB_DEV void sb_collide_list(const SbGrid &g, uint32_t count, const SbParams &prm
         if (d2 > far2) continue;            // sqrt is monotone: cannot give d < 2r, and is not 0
         const float d = sb_sqrt(d2);
         if (d == 0.0f || d < two_r) sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[id], q, vel_r[id]);
+    }
+}
+
+// The uncommon cases in one place (the callers keep them out of their main loop, so that its registers are
+// not sized by code that almost never runs): on the substep after a hash build the list is made first; a
+// pile denser than the list holds is served by the cell scan.
+SB_DEV void sb_collide_slow(const SbGrid &g, bool fresh, const SbParams &prm, float friction, float elasticity_coeff,
+                            SbParticle &particle, const SbParticle &self, uint32_t i,
+                            const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
+                            const float2 *__restrict__ vel_r)
+{
+    const uint32_t count = fresh ? sb_neighbour_list_build(g, i, self.p) : g.nl_count[i];
+    if (count == SB_NL_OVERFLOW) {
+        const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
+        sb_collide_grid(g, rg, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
+    } else {
+        sb_collide_list(g, count, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
     }
 }
 
