@@ -35,13 +35,20 @@ def parse():
     ap.add_argument("--spacing", type=float, default=30.0, help="lattice spacing d (particle radius is 10)")
     ap.add_argument("--origin-y", type=float, default=1000.0, help="y of the lattice's bottom row (10 = resting on the floor)")
     ap.add_argument("--config3", action="store_true",
-                    help="BASELINE config 3 with its contacts ACTIVE: 4000x250 lattice at spacing 22 resting on the floor "
-                         "(weight closes the lower rows to < 2r: self-collision + floor boundary), spatial-hash collisions")
+                    help="BASELINE config 3 on a lattice: 4000x250 at spacing 22 resting on the floor (floor response "
+                         "active, 8 collision candidates per particle in reach of the lists; the lattice does not "
+                         "get closer than 2r in the timed window -- see --soup for contacts that fire)")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ghost-depth", type=int, default=24,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
     ap.add_argument("--subticks", type=int, default=64)
+    ap.add_argument("--soup", action="store_true",
+                    help="config 3 with EVERY mechanism acting: width x height FREE particles (no beams) on a grid of "
+                         "--spacing (default here 40) jittered by +-10, thrown around at up to --soup-speed units/s: "
+                         "they fall, bounce off the floor and the walls and hit each other all the time "
+                         "(single GPU, spatial-hash collisions)")
+    ap.add_argument("--soup-speed", type=float, default=60.0)
     ap.add_argument("--mixed-stiffness", action="store_true",
                     help="BASELINE config 5: springs drawn from {1,3,50,500}, use with --subticks 128")
     ap.add_argument("--exchange", choices=["peer", "stream", "sync"], default="peer",
@@ -201,13 +208,22 @@ def main():
 
     if a.config3:
         a.width, a.height, a.spacing, a.origin_y, a.collisions = 4000, 250, 22.0, 10.0, "grid"
+    if a.soup:
+        a.collisions = "grid"
+        if a.spacing == 30.0:
+            a.spacing = 40.0
     W, H = a.width, a.height
     d = a.spacing
     mode = {"off": 0, "grid": 2}[a.collisions]
     path = {"auto": 0, "atomic": 1, "tiled": 2}[a.path]
     # global scene: N slabs of W columns side by side (weak scaling: per-GPU work is fixed)
     bounds = float(max(W * world, H) * d + 2000.0)
-    if world == 1:
+    if a.soup:
+        if world != 1:
+            sys.exit("--soup is a single-GPU scene")
+        buf = sb.scenes.soup_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=10.0, speed=a.soup_speed)
+        plan = None
+    elif world == 1:
         buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0, layout=2)
         plan = None
     else:
@@ -270,13 +286,20 @@ def main():
         P_total = P_local
 
     if rank == 0:
-        workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
-                    "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
-                    % ("3" if a.config3 else "2", W, H, P_local, B_local,
-                       "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else "spring 50 damp 700", a.subticks,
-                       a.collisions, "" if (d == 30.0 and a.origin_y == 1000.0) else
-                       ", spacing %g, bottom row at y=%g%s" % (d, a.origin_y, " (resting on the floor, lower rows in contact)"
-                                                               if a.config3 else "")))
+        if a.soup:
+            workload = ("BASELINE config 3 as a particle soup: %dx%d FREE particles (no beams) on a grid of %g jittered "
+                        "by +-10, velocities up to %g units/s, gravity, floor and walls, spatial-hash collisions, "
+                        "subticks %d, v2 (u32) layout" % (W, H, d, a.soup_speed, a.subticks))
+        else:
+            placed = "" if (d == 30.0 and a.origin_y == 1000.0) else ", spacing %g, bottom row at y=%g" % (d, a.origin_y)
+            if a.config3:
+                placed += " (resting on the floor: floor response active, 8 collision candidates per particle tested " \
+                          "every substep, none closer than 2r in the timed window)"
+            workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
+                        "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
+                        % ("3" if a.config3 else "2", W, H, P_local, B_local,
+                           "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else "spring 50 damp 700",
+                           a.subticks, a.collisions, placed))
         copies = eng.info("beam_copies")
         alg_bytes = 52.0 * B_local + 48.0 * P_local  # per substep, one launch
         roof = None

@@ -80,13 +80,15 @@ typedef struct sb_options {
     uint32_t tile_particles; /* SB_PATH_TILED: target particles per tile (0 = default) */
     int32_t device_ordinal;  /* HIP device */
     float grid_skin;         /* SB_COLLIDE_GRID: cells are 2r + 2*skin wide and the hash is rebuilt only when
-                              * some particle may have moved more than `skin` since the last build;
-                              * 0 = default (0.4 r), negative = rebuild every substep */
+                              * some particle may have moved more than `skin` (relative to the scene's common
+                              * drift) since the last build.  0 = default: adaptive, starting at 0.4 r and
+                              * doubling up to 1.6 r while hashes last 2 substeps or less; > 0 = that skin,
+                              * fixed; negative = rebuild every substep */
     uint32_t reserved[4];
 } sb_options;
 
 /* Fill with the reference defaults: bounds 1000, radius 10, subticks 64, 65536/65536, v1,
- * all-pairs, auto path, device 0. */
+ * spatial-hash collisions (the bits of the reference's all-pairs scan), auto path, device 0. */
 void sb_default_options(sb_options *opts);
 
 /* Replaces the WGPUSoftbodyEngineWorker constructor's device/buffer/pipeline creation

@@ -461,10 +461,13 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         }
         e->grid.x0 = x0;
         e->grid.y0 = y0;
-        e->grid.cell = cell;
-        e->grid.nx = std::max(1u, (uint32_t)std::ceil((double)(x1 - x0) / cell));
-        e->grid.ny = std::max(1u, (uint32_t)std::ceil((double)(y1 - y0) / cell));
-        e->ncell = e->grid.nx * e->grid.ny;
+        e->grid.width = x1 - x0;
+        e->grid.height = y1 - y0;
+        e->grid.two_r = e->prm.particle_radius * 2.0f;
+        e->grid.cell_min = cell;
+        e->grid.nx_cap = std::max(1u, (uint32_t)std::ceil((double)(x1 - x0) / cell));
+        e->grid.ny_cap = std::max(1u, (uint32_t)std::ceil((double)(y1 - y0) / cell));
+        e->ncell = e->grid.nx_cap * e->grid.ny_cap; // capacity: the skin only ever makes cells larger than cell_min
         const size_t n1 = (size_t)e->ncell + 1;
         SB_TRY(dev_alloc(e, &e->d_cell_cnt, n1));
         SB_HIP(e, hipMemset(e->d_cell_cnt, 0, n1 * 4));
@@ -483,22 +486,29 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_TRY(dev_alloc(e, &e->d_grid_bar, 1));
         SB_HIP(e, hipMemset(e->d_grid_bar, 0, 4));
         SbGridCtl ctl[2] = {};
-        ctl[0].force = ctl[1].force = 1;
-        ctl[0].skin = ctl[1].skin = skin;
+        for (int k = 0; k < 2; k++) {
+            ctl[k].force = 1;
+            ctl[k].skin = ctl[k].skin_min = skin;
+            // grid_skin given explicitly: that skin, fixed.  Default: adaptive between 0.4 r and 1.6 r (SbGridCtl).
+            ctl[k].skin_max = e->opt.grid_skin > 0.f ? skin : 4.0f * skin;
+            ctl[k].cell = cell;
+            ctl[k].nx = e->grid.nx_cap;
+            ctl[k].ny = e->grid.ny_cap;
+            const float reach = e->grid.two_r + 2.0f * skin;
+            ctl[k].reach2 = reach * reach * 1.001f;
+            ctl[k].since = 1000; // "the hash before the first one lasted long": start lean
+        }
         SB_HIP(e, hipMemcpy(e->d_grid_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
         e->grid_par = 0;
         e->grid.cell_start = e->d_cell_start;
         e->grid.rec = e->d_rec;
         e->grid.cell_of = e->d_cell_of;
-        e->grid.skin = skin;
         SB_TRY(dev_alloc(e, &e->d_nl_count, P));
         SB_TRY(dev_alloc(e, &e->d_nl, (size_t)SB_NL_CAP * std::max<size_t>(P, 1)));
         SB_HIP(e, hipMemset(e->d_nl_count, 0, std::max<size_t>(P, 1) * 4));
         e->grid.nl_count = e->d_nl_count;
         e->grid.nl = e->d_nl;
         e->grid.nl_stride = P;
-        const float reach = e->prm.particle_radius * 2.0f + 2.0f * skin;
-        e->grid.nl_reach2 = reach * reach * 1.001f;
         e->grid.ctl = &e->d_grid_ctl[0];
     }
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
@@ -744,6 +754,15 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             SB_HIP(e, hipStreamSynchronize(e->stream));
             SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
             *value = ctl.builds;
+        }
+    }
+    else if (k == "grid_skin_x1000") { // the skin of the current hash, in thousandths of a unit (it adapts)
+        *value = 0;
+        if (e->d_grid_ctl) {
+            SbGridCtl ctl;
+            SB_HIP(e, hipStreamSynchronize(e->stream));
+            SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
+            *value = (uint64_t)(ctl.skin * 1000.0f + 0.5f);
         }
     }
     else if (k == "material_mode") *value = e->mat_mode;

@@ -464,6 +464,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     const uint32_t builds = SB_AGENT_LOAD(&cin->builds), force = SB_AGENT_LOAD(&cin->force);
     const float c_used_x = SB_AGENT_LOAD(&cin->cx), c_used_y = SB_AGENT_LOAD(&cin->cy); // what the last substep used
     const float C_in_x = SB_AGENT_LOAD(&cin->Cx), C_in_y = SB_AGENT_LOAD(&cin->Cy);
+    const SbGridGeom geom_in = sb_grid_geom_load(cin);
+    const uint32_t since = SB_AGENT_LOAD(&cin->since);
+    const float skin_min = SB_AGENT_LOAD(&cin->skin_min), skin_max = SB_AGENT_LOAD(&cin->skin_max);
     float m = 0.0f, sx = 0.0f, sy = 0.0f;
     for (uint32_t i = tid; i < nblk; i += SB_MT) { // per-lane addresses: vector loads
         m = fmaxf(m, __uint_as_float(blk_max[i]));
@@ -490,6 +493,13 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     }
     const float accum = accum_in + step; // bound for the READ state of this substep
     const bool rebuild = force != 0u || !(accum <= skin); // NaN-safe
+    // the skin of the hash about to be built follows how long the last one lasted (SbGridCtl)
+    float skin_new = skin;
+    if (rebuild && force == 0u) {
+        if (since <= 2u) skin_new = fminf(skin * 2.0f, skin_max);
+        else if (since >= 64u) skin_new = fmaxf(skin * 0.5f, skin_min);
+    }
+    const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new) : geom_in;
     // the common displacement the coming substep is measured against: the mean of the one just done
     float mean_x = tot_x / (float)nblk, mean_y = tot_y / (float)nblk; // one sample particle per workgroup
     if (!(sb_abs(mean_x) < 1.0e30f) || !(sb_abs(mean_y) < 1.0e30f)) mean_x = mean_y = 0.0f;
@@ -498,7 +508,14 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         SB_AGENT_STORE(&cout->rebuild, rebuild ? 1u : 0u);
         SB_AGENT_STORE(&cout->force, 0u);
         SB_AGENT_STORE(&cout->accum, rebuild ? 0.0f : accum);
-        SB_AGENT_STORE(&cout->skin, skin);
+        SB_AGENT_STORE(&cout->skin, geo.skin);
+        SB_AGENT_STORE(&cout->cell, geo.cell);
+        SB_AGENT_STORE(&cout->reach2, geo.reach2);
+        SB_AGENT_STORE(&cout->nx, geo.nx);
+        SB_AGENT_STORE(&cout->ny, geo.ny);
+        SB_AGENT_STORE(&cout->since, rebuild ? 1u : since + 1u);
+        SB_AGENT_STORE(&cout->skin_min, skin_min);
+        SB_AGENT_STORE(&cout->skin_max, skin_max);
         SB_AGENT_STORE(&cout->builds, builds + (rebuild ? 1u : 0u));
         SB_AGENT_STORE(&cout->cx, mean_x);
         SB_AGENT_STORE(&cout->cy, mean_y);
@@ -522,7 +539,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            c[u] = sb_grid_coord(p[u].y, g.y0, g.cell, g.ny) * g.nx + sb_grid_coord(p[u].x, g.x0, g.cell, g.nx);
+            c[u] = sb_grid_coord(p[u].y, g.y0, geo.cell, geo.ny) * geo.nx + sb_grid_coord(p[u].x, g.x0, geo.cell, geo.nx);
 #pragma unroll
         for (int u = 0; u < 4; u++)
             if (i0 + (uint32_t)u * nthreads < P) rk[u] = atomicAdd(&w.cell_cnt[c[u]], 1u);

@@ -234,7 +234,8 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
 // ---------------------------------------------------------------- spatial hash (SB_COLLIDE_GRID)
 
 // Uniform grid over [x0, x0 + nx*cell) x [y0, y0 + ny*cell); coordinates outside are clamped into
-// the edge cells.  The map x -> cell coordinate is monotone and cell >= 2r * (1 + 1/64), so two
+// the edge cells.  The origin and the extent are fixed at upload; the cell size (with it nx, ny) belongs to
+// the CURRENT hash and lives in SbGridCtl, because the skin adapts to how fast the scene moves.  The map x -> cell coordinate is monotone and cell >= 2r * (1 + 1/64), so two
 // particles closer than 2r always land in the same or adjacent cells: the 3x3 neighbourhood is a
 // SUPERSET of the interacting pairs of compute.wgsl:144-170 wherever the particles are (clamping
 // only piles far-away particles into edge cells: slower, never wrong).
@@ -242,8 +243,9 @@ struct SbGrid {
     const uint32_t *cell_start; // per cell (+1 spare entry): absolute index of its first record
     const float4 *rec;          // sorted by cell: {x, y AT BUILD TIME, bits(slot), bits(internal index)}
     const uint32_t *cell_of;    // per particle: its cell at the last build
-    float x0, y0, cell, skin;
-    uint32_t nx, ny;
+    float x0, y0, width, height;
+    float two_r, cell_min;      // cells are never smaller than cell_min (what the arrays were sized for)
+    uint32_t nx_cap, ny_cap;
     // neighbour lists (sb_neighbour_list_build): per particle the internal indices of everybody within
     // 2r + 2*skin at build time, in ascending slot order; entry k of particle i at nl[k * nl_stride + i].
     // Written by the particle kernel of the substep that follows a hash build (*fresh != 0: every particle
@@ -252,7 +254,6 @@ struct SbGrid {
     uint32_t *nl_count;         // entries, or SB_NL_OVERFLOW: more than SB_NL_CAP, scan the cells instead
     uint32_t *nl;
     uint32_t nl_stride;
-    float nl_reach2;            // (2r + 2*skin)^2 with a rounding margin
     const struct SbGridCtl *ctl; // what the k_grid_maintain launch just before this kernel published
 };
 #define SB_NL_CAP 16u
@@ -278,11 +279,46 @@ struct SbGridCtl {
     uint32_t builds;  // statistics
     float cx, cy;     // c for the coming substep
     float Cx, Cy;     // C for the READ state of the coming substep
+    // geometry of the current hash.  The skin ADAPTS at every build: when the last hash lasted 2 substeps or less
+    // it doubles (up to skin_max), when it lasted 64 or more it halves (down to skin_min): a scene that moves
+    // fast gets fatter cells and longer lists instead of a rebuild per substep, a quiet one gets them lean again.
+    float cell, reach2; // cell width 2r*(1+1/64) + 2*skin (>= cell_min); (2r + 2*skin)^2 with a rounding margin
+    uint32_t nx, ny;
+    uint32_t since;     // substeps the current hash has served
+    float skin_min, skin_max;
+};
+struct SbGridGeom {
+    float skin, cell, reach2;
+    uint32_t nx, ny;
 };
 #define SB_SCAN_BLOCK 2048u
 #define SB_MAX_WAVES 16
 #define SB_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SB_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+SB_DEV SbGridGeom sb_grid_geom_load(const SbGridCtl *c)
+{
+    SbGridGeom m;
+    m.skin = SB_AGENT_LOAD(&c->skin);
+    m.cell = SB_AGENT_LOAD(&c->cell);
+    m.reach2 = SB_AGENT_LOAD(&c->reach2);
+    m.nx = SB_AGENT_LOAD(&c->nx);
+    m.ny = SB_AGENT_LOAD(&c->ny);
+    return m;
+}
+// the geometry that goes with a skin (every workgroup of k_grid_maintain computes the same values)
+SB_DEV SbGridGeom sb_grid_geom_for(const SbGrid &g, float skin)
+{
+    SbGridGeom m;
+    m.skin = skin;
+    m.cell = fmaxf(g.two_r * 1.015625f + 2.0f * skin, g.cell_min);
+    const float reach = g.two_r + 2.0f * skin;
+    m.reach2 = reach * reach * 1.001f;
+    const float fx = ceilf(sb_div(g.width, m.cell)), fy = ceilf(sb_div(g.height, m.cell));
+    m.nx = fx >= 1.0f ? (fx < (float)g.nx_cap ? (uint32_t)fx : g.nx_cap) : 1u; // never more cells than allocated
+    m.ny = fy >= 1.0f ? (fy < (float)g.ny_cap ? (uint32_t)fy : g.ny_cap) : 1u;
+    return m;
+}
 
 // End of the particle kernel, called by EVERY thread of the block: this block's largest drift-relative
 // displacement goes to blk[blockIdx.x] (float bits; anything not provably small reads as huge).  One plain slot
@@ -323,16 +359,16 @@ SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
 struct SbGridRanges {
     uint32_t b[3], e[3];
 };
-SB_DEV SbGridRanges sb_grid_ranges(const SbGrid &g, uint32_t cell)
+SB_DEV SbGridRanges sb_grid_ranges(const SbGrid &g, const SbGridGeom &m, uint32_t cell)
 {
     SbGridRanges rg;
-    const uint32_t cx = cell % g.nx, cy = cell / g.nx;
-    const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < g.nx ? cx + 1u : g.nx - 1u;
+    const uint32_t cx = cell % m.nx, cy = cell / m.nx;
+    const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < m.nx ? cx + 1u : m.nx - 1u;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const int yy = (int)cy + r - 1;
-        const bool in = yy >= 0 && yy < (int)g.ny;
-        const uint32_t row = in ? (uint32_t)yy * g.nx : 0u;
+        const bool in = yy >= 0 && yy < (int)m.ny;
+        const uint32_t row = in ? (uint32_t)yy * m.nx : 0u;
         const uint32_t b = g.cell_start[row + xa], e = g.cell_start[row + xb + 1u]; // one spare entry at the end
         rg.b[r] = in ? b : 0u;
         rg.e[r] = in ? e : 0u;
@@ -344,14 +380,14 @@ SB_DEV SbGridRanges sb_grid_ranges(const SbGrid &g, uint32_t cell)
 // contacts in ASCENDING SLOT ORDER exactly like the all-pairs scan does: repeatedly pick the
 // contact with the smallest slot above the last one applied.  Non-contacts are no-ops in the
 // reference loop, so skipping them changes nothing; the result is bit-identical to all-pairs.
-SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbParams &prm, float friction,
+SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRanges &rg, const SbParams &prm, float friction,
                             float elasticity_coeff, SbParticle &particle, const SbParticle &self, uint32_t i,
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
                             const float2 *__restrict__ vel_r)
 {
     const float two_r = prm.particle_radius * 2.0f;
     const float far2 = two_r * two_r * 1.001f;
-    const float reach = two_r + g.skin, stale_far2 = reach * reach * 1.001f;
+    const float reach = two_r + m.skin, stale_far2 = reach * reach * 1.001f;
     // where this particle would be in the frame of the build: current position minus the common drift
     const float qx = self.p.x - SB_AGENT_LOAD(&g.ctl->Cx), qy = self.p.y - SB_AGENT_LOAD(&g.ctl->Cy);
     bool have_last = false;
@@ -399,10 +435,10 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridRanges &rg, const SbPar
 // in ascending slot order (repeated selection of the smallest slot above the last one taken, as above).
 // While the displacement bound D <= skin, a pair closer than 2r NOW was closer than 2r + 2D at build time,
 // so the list is a superset of i's contacts until the next build.  NaN distances are kept (conservative).
-SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, uint32_t i, float2 p)
+SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, uint32_t i, float2 p)
 {
-    const float reach2 = g.nl_reach2;
-    const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
+    const float reach2 = m.reach2;
+    const SbGridRanges rg = sb_grid_ranges(g, m, g.cell_of[i]);
     uint32_t n = 0u, last = 0u;
     bool have_last = false;
     for (;;) {
@@ -462,10 +498,11 @@ SB_DEV void sb_collide_slow(const SbGrid &g, bool fresh, const SbParams &prm, fl
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
                             const float2 *__restrict__ vel_r)
 {
-    const uint32_t count = fresh ? sb_neighbour_list_build(g, i, self.p) : g.nl_count[i];
+    const SbGridGeom m = sb_grid_geom_load(g.ctl); // only these paths need the geometry of the current hash
+    const uint32_t count = fresh ? sb_neighbour_list_build(g, m, i, self.p) : g.nl_count[i];
     if (count == SB_NL_OVERFLOW) {
-        const SbGridRanges rg = sb_grid_ranges(g, g.cell_of[i]);
-        sb_collide_grid(g, rg, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
+        const SbGridRanges rg = sb_grid_ranges(g, m, g.cell_of[i]);
+        sb_collide_grid(g, m, rg, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
     } else {
         sb_collide_list(g, count, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
     }

@@ -106,6 +106,23 @@ def lattice_buffers(w, h, d=30.0, origin=(1000.0, 1000.0), spring=50.0, damp=700
     return buf
 
 
+def soup_buffers(w, h, d=40.0, origin=(1000.0, 1000.0), jitter=10.0, speed=60.0, seed=1, layout=LAYOUT_V2):
+    """w*h FREE particles (no beams): a grid of spacing d jittered by +-jitter, each thrown in a random
+    direction at up to `speed` units/s (hash_uniform draws).  With gravity, the floor and the walls this is a
+    scene in which the whole collision path of compute.wgsl:142-170 keeps firing."""
+    n = w * h
+    xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+    u = hash_uniform(seed, 4 * n).reshape(n, 4)
+    pv = np.zeros((n, 6), dtype="<f4")
+    pv[:, 0] = (xs.reshape(-1) * float(d) + float(origin[0]) + u[:, 0] * jitter).astype("<f4")
+    pv[:, 1] = (ys.reshape(-1) * float(d) + float(origin[1]) + u[:, 1] * jitter).astype("<f4")
+    pv[:, 2] = (u[:, 2] * speed).astype("<f4")
+    pv[:, 3] = (u[:, 3] * speed).astype("<f4")
+    buf = Buffers(layout, n, 4)
+    buf.set_scene(pv, np.zeros(0, dtype=BEAM_DTYPE[layout]))
+    return buf
+
+
 def hash_uniform(seed, n):
     """Documented integer hash -> uniform [-1, 1) doubles (no Math.random).
     splitmix64 of (seed*2^32 + i)."""

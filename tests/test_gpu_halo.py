@@ -117,6 +117,61 @@ def test_peer_exchange_in_process_equals_single_engine(sb, world, depth):
         assert beams[int(k)] == rec.tobytes()[8:]
 
 
+@pytest.mark.parametrize("world,depth", [(2, 4), (3, 6)])
+def test_collisions_across_slab_faces(sb, world, depth):
+    """Spatial-hash collisions with sharding: ghost particles are ordinary particles of the rank's scene, so a
+    contact between an owned particle and a ghost is computed on both ranks from the same inputs, in the same
+    ascending-slot order (local data indices are a monotone map of the global ones).  Lattice at spacing 30
+    with jitter 5.5 (some neighbours start closer than 2r = 20, also across the faces), thrown at the floor;
+    the scene stays gentle (a lattice PACKED below 2r bursts, and a burst outruns any ghost zone)."""
+    halo = sb.halo
+    W, H, steps = 24, 32, 72
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=5.5, velocity=(0.2, -6.0), strain_limit=1e9)
+
+    def engine_for(buf, mode):
+        e = sb.Engine(bounds_size=4000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                      collision_mode=mode, path=2, tile_particles=256)
+        e.write_buffers(buf)
+        return e
+
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    want = {}
+    for mode in (0, 2):
+        ref = engine_for(gbuf, mode)
+        ref.step(steps)
+        want[mode] = ref.load_buffers(gbuf.copy())
+        ref.destroy()
+    assert np.isfinite(want[2].particles).all()
+    assert (want[0].particles != want[2].particles).any(axis=1).mean() > 0.5   # the contacts really acted
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng = engine_for(buf, 2)
+        exs.append(halo.PeerExchanger(eng, plan, timeout_ms=3000))
+        made.append((buf, plan, eng))
+    for ex in exs:
+        ex.connect([x.card for x in exs])
+    done = 0
+    while done < steps:
+        m = min(depth, steps - done)
+        for ex in exs:
+            ex.step(m)
+        done += m
+    parts = np.zeros_like(want[2].particles)
+    beams = {}
+    for buf, plan, eng in made:
+        eng.sync()
+        out = eng.load_buffers(buf.copy())
+        gid, prt, bkey, brec = halo.gather_owned(plan, out)
+        parts[gid] = prt
+        for k, rec in zip(bkey, brec):
+            beams[int(k)] = rec.tobytes()[8:]
+        eng.destroy()
+    assert np.array_equal(parts.view("u4"), want[2].particles.view("u4"))
+    for k, rec in zip(gplan.global_beam_key, want[2].beams):
+        assert beams[int(k)] == rec.tobytes()[8:]
+
+
 def test_peer_wait_gives_up_instead_of_hanging(sb):
     """A neighbour that never posts: the bounded wait ends, sb_sync reports it, the engine stays usable."""
     halo = sb.halo
