@@ -10,9 +10,10 @@ target_length/last_length of every ghost beam.  One exchange per `depth` substep
 per substep: the exchange is latency-bound (a few hundred KB over 2 of the 7 xGMI links), so
 amortising it is what keeps weak scaling near-linear; the price is depth/W redundant work.
 
-The only collective on the data path is the neighbour send/recv (RCCL through torch.distributed,
-ordered on the engine's own HIP stream); there is no all-reduce.  Collisions across slab faces
-are not handled here (BASELINE configs 4-5 derive from config 2: collisions off).
+The only exchange on the data path is with the two neighbours: direct stores into their IPC-mapped
+mailboxes (PeerExchanger, sb_peer_*), or RCCL send/recv through torch.distributed ordered on the
+engine's own HIP stream (Exchanger + TorchTransport); there is no all-reduce.  Collisions across slab
+faces need nothing extra: ghosts are ordinary particles of the rank's scene (tests/test_gpu_halo.py).
 """
 import numpy as np
 
