@@ -212,6 +212,8 @@ def main():
         a.collisions = "grid"
         if a.spacing == 30.0:
             a.spacing = 40.0
+        if a.origin_y == 1000.0:
+            a.origin_y = 30.0       # bottom rows within reach of the floor
     W, H = a.width, a.height
     d = a.spacing
     mode = {"off": 0, "grid": 2}[a.collisions]

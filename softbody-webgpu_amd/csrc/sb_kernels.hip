@@ -496,8 +496,15 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     // the skin of the hash about to be built follows how long the last one lasted (SbGridCtl)
     float skin_new = skin;
     if (rebuild && force == 0u) {
-        if (since <= 2u) skin_new = fminf(skin * 2.0f, skin_max);
-        else if (since >= 64u) skin_new = fmaxf(skin * 0.5f, skin_min);
+        if (since <= 3u) {
+            // short-lived hash: a doubled skin must promise at least two substeps at the rate the bound has been
+            // growing, else the scene is simply too violent for any hash to last and lean cells are the cheapest
+            const float rate = accum / (float)since, wider = fminf(skin * 2.0f, skin_max);
+            if (wider >= 2.0f * rate) skin_new = wider;
+            else if (!(skin >= 2.0f * rate)) skin_new = skin_min;
+        } else if (since >= 64u) {
+            skin_new = fmaxf(skin * 0.5f, skin_min);
+        }
     }
     const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new) : geom_in;
     // the common displacement the coming substep is measured against: the mean of the one just done

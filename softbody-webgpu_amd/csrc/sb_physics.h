@@ -279,9 +279,11 @@ struct SbGridCtl {
     uint32_t builds;  // statistics
     float cx, cy;     // c for the coming substep
     float Cx, Cy;     // C for the READ state of the coming substep
-    // geometry of the current hash.  The skin ADAPTS at every build: when the last hash lasted 2 substeps or less
-    // it doubles (up to skin_max), when it lasted 64 or more it halves (down to skin_min): a scene that moves
-    // fast gets fatter cells and longer lists instead of a rebuild per substep, a quiet one gets them lean again.
+    // geometry of the current hash.  The skin ADAPTS at every build: when the last hash lasted 3 substeps or less
+    // it doubles (up to skin_max) provided that promises two substeps at the rate the bound has been growing --
+    // if not even that, the scene is too violent for any hash to last and the skin drops back to skin_min; when
+    // a hash lasted 64 substeps or more the skin halves (down to skin_min).  A scene that moves fast gets fatter
+    // cells and longer lists instead of a rebuild per substep, a quiet one gets them lean again.
     float cell, reach2; // cell width 2r*(1+1/64) + 2*skin (>= cell_min); (2r + 2*skin)^2 with a rounding margin
     uint32_t nx, ny;
     uint32_t since;     // substeps the current hash has served
@@ -393,8 +395,9 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRa
     bool have_last = false;
     uint32_t last = 0u;
     for (;;) {
-        uint32_t best_slot = 0xFFFFFFFFu, best_id = 0u;
-        float2 best_p = make_float2(0.f, 0.f);
+        // one sweep collects the FOUR contacts with the smallest slots above `last` (sorted insert into four
+        // registers); they are then applied in that order.  A pile of K contacts costs K/4 sweeps, not K.
+        uint32_t bs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bi[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             for (uint32_t k0 = rg.b[r]; k0 < rg.e[r]; k0 += 4u) {
@@ -405,8 +408,8 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRa
                                                          : make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t slot = __float_as_uint(rc[j].z), id = __float_as_uint(rc[j].w);
-                    if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
+                    uint32_t slot = __float_as_uint(rc[j].z), id = __float_as_uint(rc[j].w);
+                    if (id == i || (have_last && slot <= last) || slot >= bs[3]) continue;
                     const float sx = rc[j].x - qx, sy = rc[j].y - qy;
                     if (sx * sx + sy * sy > stale_far2) continue; // cannot have come within 2r (see SbGridCtl)
                     const float2 q = pos_r[id];
@@ -416,18 +419,32 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRa
                     // correctly rounded root is only evaluated for the few candidates near contact range
                     if (d2 > far2) continue;
                     const float d = sb_sqrt(d2);
-                    if (d == 0.0f || d < two_r) {
-                        best_slot = slot;
-                        best_id = id;
-                        best_p = q;
+                    if (!(d == 0.0f || d < two_r)) continue;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) { // carry the larger one down the four registers
+                        const bool lt = slot < bs[q4];
+                        const uint32_t ts = lt ? bs[q4] : slot, ti = lt ? bi[q4] : id;
+                        bs[q4] = lt ? slot : bs[q4];
+                        bi[q4] = lt ? id : bi[q4];
+                        slot = ts;
+                        id = ti;
                     }
                 }
             }
         }
-        if (best_slot == 0xFFFFFFFFu) break;
-        sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[best_id], best_p, vel_r[best_id]);
-        last = best_slot;
-        have_last = true;
+        bool full = true;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            if (bs[q4] == 0xFFFFFFFFu) {
+                full = false;
+            } else {
+                sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[bi[q4]], pos_r[bi[q4]],
+                                vel_r[bi[q4]]);
+                last = bs[q4];
+                have_last = true;
+            }
+        }
+        if (!full) break; // fewer than four contacts left above `last`
     }
 }
 
@@ -442,28 +459,45 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
     uint32_t n = 0u, last = 0u;
     bool have_last = false;
     for (;;) {
-        uint32_t best_slot = 0xFFFFFFFFu, best_id = 0u;
+        // one sweep over the candidates collects the FOUR smallest slots above `last` (sorted insert into four
+        // registers), so a typical list of 4-8 entries costs two or three sweeps instead of one per entry
+        uint32_t bs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bi[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             for (uint32_t k = rg.b[r]; k < rg.e[r]; k++) {
                 const float4 rc = g.rec[k];
-                const uint32_t slot = __float_as_uint(rc.z), id = __float_as_uint(rc.w);
-                if (id == i || (have_last && slot <= last) || slot >= best_slot) continue;
+                uint32_t slot = __float_as_uint(rc.z), id = __float_as_uint(rc.w);
+                if (id == i || (have_last && slot <= last) || slot >= bs[3]) continue;
                 const float dx = rc.x - p.x, dy = rc.y - p.y;
                 if (dx * dx + dy * dy > reach2) continue;
-                best_slot = slot;
-                best_id = id;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { // carry the larger one down the four registers
+                    const bool lt = slot < bs[q];
+                    const uint32_t ts = lt ? bs[q] : slot, ti = lt ? bi[q] : id;
+                    bs[q] = lt ? slot : bs[q];
+                    bi[q] = lt ? id : bi[q];
+                    slot = ts;
+                    id = ti;
+                }
             }
         }
-        if (best_slot == 0xFFFFFFFFu) break;
-        if (n == SB_NL_CAP) {
-            n = SB_NL_OVERFLOW;
-            break;
+        bool full = true;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (bs[q] == 0xFFFFFFFFu) {
+                full = false;
+            } else if (n != SB_NL_OVERFLOW) {
+                if (n == SB_NL_CAP) {
+                    n = SB_NL_OVERFLOW;
+                } else {
+                    g.nl[n * g.nl_stride + i] = bi[q];
+                    n++;
+                    last = bs[q];
+                    have_last = true;
+                }
+            }
         }
-        g.nl[n * g.nl_stride + i] = best_id;
-        n++;
-        last = best_slot;
-        have_last = true;
+        if (!full || n == SB_NL_OVERFLOW) break; // fewer than four left above `last`: that was everybody
     }
     g.nl_count[i] = n;
     return n;

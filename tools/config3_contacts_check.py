@@ -8,7 +8,7 @@ import __graft_entry__ as ge
 sb = ge.load_package()
 scenes = {
     "--config3 (4000x250 lattice, spacing 22, on the floor)": (lambda: sb.scenes.lattice_buffers(4000, 250, d=22.0, origin=(1000.0, 10.0), jitter=1.0, layout=2), 4000 * 22.0 + 2000.0),
-    "--soup (1000x1000 free particles, spacing 40, up to 60 units/s)": (lambda: sb.scenes.soup_buffers(1000, 1000, d=40.0, origin=(1000.0, 1000.0), jitter=10.0, speed=60.0), 1000 * 40.0 + 2000.0),
+    "--soup (1000x1000 free particles, spacing 40, up to 60 units/s)": (lambda: sb.scenes.soup_buffers(1000, 1000, d=40.0, origin=(1000.0, 30.0), jitter=10.0, speed=60.0), 1000 * 40.0 + 2000.0),
 }
 for name, (make, bounds) in scenes.items():
     buf = make()

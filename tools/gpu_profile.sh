@@ -25,6 +25,8 @@ python3 $OLDPWD/bench.py --collisions grid --no-cpu-baseline > $OUT/bench_grid.j
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grid -- python3 $OLDPWD/bench.py --collisions grid --steps 200 --warmup 16 --no-cpu-baseline > $OUT/trace_grid.log 2>&1 || { echo grid trace failed; exit 1; }
 # config 3 with its contacts active (4000x250 lattice at spacing 22 resting on the floor)
 python3 $OLDPWD/bench.py --config3 --no-cpu-baseline > $OUT/bench_config3_contacts.json 2>/dev/null || echo "config3 contacts bench failed"
+python3 $OLDPWD/bench.py --soup --no-cpu-baseline > $OUT/bench_soup.json 2>/dev/null || echo "soup bench failed"
+python3 $OLDPWD/tools/config3_contacts_check.py 2>/dev/null | grep -v "amdgpu.ids" > $OUT/config3_contacts_check.txt || echo "config3 check failed"
 # one GPU's share of BASELINE configs 4 (500 x 4000 columns x rows) and 5 (1000 x 8000, mixed springs, dt = 1/128)
 python3 $OLDPWD/bench.py --no-cpu-baseline --width 500 --height 4000 --steps 500 > $OUT/cfg4_share.json 2>/dev/null || echo "cfg4 share failed"
 python3 $OLDPWD/bench.py --no-cpu-baseline --width 1000 --height 8000 --mixed-stiffness --subticks 128 --steps 200 --warmup 32 > $OUT/cfg5_share.json 2>/dev/null || echo "cfg5 share failed"

@@ -56,7 +56,8 @@ if os.path.exists(bg):
 for name, out in (("exchange_cost.txt", "%s_exchange_cost.txt"), ("rehearse_2ranks.json", "%s_rehearse_2ranks_one_gpu.json"),
                   ("node_bench.json", "%s_node_bench.json"), ("cfg4_share.json", "%s_cfg4_share.json"),
                   ("cfg5_share.json", "%s_cfg5_share.json"),
-                  ("bench_config3_contacts.json", "%s_bench_config3_contacts.json")):
+                  ("bench_config3_contacts.json", "%s_bench_config3_lattice_on_floor.json"),
+                  ("bench_soup.json", "%s_bench_soup.json"), ("config3_contacts_check.txt", "%s_config3_contacts_check.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, out % tag))
