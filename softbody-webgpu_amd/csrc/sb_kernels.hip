@@ -445,7 +445,7 @@ SB_DEV void sb_grid_barrier(uint32_t *bar, uint32_t target, uint32_t *err)
 struct SbGridBuild {
     uint32_t *cell_cnt, *cell_scan, *block_off, *rank, *cell_of, *cell_start;
     float4 *rec;
-    uint32_t ncell1, nchunks;
+    uint32_t ncell1_cap;
     uint32_t *bar, *err;
 };
 
@@ -532,6 +532,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     if (!rebuild) return;
 
     const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
+    // the cells of THIS hash (a wide skin means far fewer than the arrays were sized for; every count beyond them is
+    // zero, because each build re-zeroes exactly the cells it counted into)
+    const uint32_t ncell1 = min(geo.nx * geo.ny + 1u, w.ncell1_cap), nchunks = (ncell1 + SB_MT_CHUNK - 1u) / SB_MT_CHUNK;
     const uint32_t bar0 = builds * 3u * gridDim.x; // arrivals before this build (three barriers per build)
     // ---- counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
     // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
@@ -561,13 +564,13 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     }
     sb_grid_barrier(w.bar, bar0 + gridDim.x, w.err);
     // ---- exclusive scan of each 8192-cell chunk (1024 threads x 8 cells) + the chunk totals; clears the counts
-    for (uint32_t chunk = blockIdx.x; chunk < w.nchunks; chunk += gridDim.x) {
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t base = chunk * SB_MT_CHUNK + tid * 8u;
         uint32_t v[8], sum = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             uint32_t x = 0u;
-            if (base + k < w.ncell1) {
+            if (base + k < ncell1) {
                 x = SB_AGENT_LOAD(&w.cell_cnt[base + k]);
                 w.cell_cnt[base + k] = 0u; // ready for the next build
             }
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         const uint32_t excl = wave_off + inc - sum;
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (base + k < w.ncell1) w.cell_scan[base + k] = v[k] + excl;
+            if (base + k < ncell1) w.cell_scan[base + k] = v[k] + excl;
         if (tid == SB_MT - 1) w.block_off[chunk] = excl + sum;
         __syncthreads();
     }
@@ -596,8 +599,8 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     if (blockIdx.x == 0) {
         if (tid == 0) s_carry = 0;
         __syncthreads();
-        for (uint32_t base = 0; base < w.nchunks; base += SB_MT) {
-            const uint32_t x = base + tid < w.nchunks ? w.block_off[base + tid] : 0u;
+        for (uint32_t base = 0; base < nchunks; base += SB_MT) {
+            const uint32_t x = base + tid < nchunks ? w.block_off[base + tid] : 0u;
             uint32_t inc = x;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             __syncthreads();
             uint32_t wave_off = s_carry;
             for (uint32_t k = 0; k < (tid >> 6); k++) wave_off += s_wave[k];
-            if (base + tid < w.nchunks) w.block_off[base + tid] = wave_off + inc - x;
+            if (base + tid < nchunks) w.block_off[base + tid] = wave_off + inc - x;
             __syncthreads();
             if (tid == SB_MT - 1) s_carry = wave_off + inc;
             __syncthreads();
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             if (i < P) w.rec[at[u]] = make_float4(p[u].x, p[u].y, __uint_as_float(slot[u]), __uint_as_float(i));
         }
     }
-    for (uint32_t c = gtid; c < w.ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
+    for (uint32_t c = gtid; c < ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -798,7 +801,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
         }();
         const uint32_t blocks = std::min(std::max(work, 1u), max_blocks);
         SbGridBuild gb{e->d_cell_cnt, e->d_cell_scan, e->d_block_off, e->d_rank, e->d_cell_of, e->d_cell_start,
-                       e->d_rec, n, nchunks, e->d_grid_bar, e->dev_err};
+                       e->d_rec, n, e->d_grid_bar, e->dev_err};
         k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
                                                             r.pos, e->d_pslot, e->P, e->grid, gb);
         e->grid_par ^= 1u;
