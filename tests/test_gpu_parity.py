@@ -252,6 +252,31 @@ def test_grid_dense_pile_overflows_neighbour_lists(sb, oracle, path):
     assert_same(got, exp, "dense pile path %d" % path)
 
 
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_fast_gas_adapts_its_skin(sb, oracle, path):
+    """1444 free particles (grid of 36 jittered by 7) flying at up to 60 units/s per axis (1.3 units per substep, contacts kick some to 3) in a 1400 box for 240
+    substeps: hashes with the default skin last one or two substeps, so the skin doubles (twice), cells and
+    list reach change on the fly -- and the result is still the all-pairs scan's, bit for bit."""
+    buf = sb.scenes.soup_buffers(38, 38, d=36.0, origin=(30.0, 30.0), jitter=7.0, speed=60.0, seed=31)  # nobody overlaps at t=0
+    P = buf.particle_count
+    eng = sb.Engine(bounds_size=1400.0, layout=2, max_particles=P, max_beams=4, collision_mode=GRID, path=path, tile_particles=128)
+    ref = oracle.OracleEngine(1400.0, 10.0, 64, 2, ALLPAIRS, threads=8)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    skins = set()
+    for _ in range(6):
+        eng.step(40)
+        ref.step(40)
+        skins.add(eng.info("grid_skin_x1000"))
+    got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+    builds = eng.info("grid_builds")
+    eng.destroy()
+    assert np.isfinite(exp.particles).all()
+    assert_same(got, exp, "fast gas path %d" % path)
+    assert max(skins) >= 8000, (skins, builds)   # the skin grew from its default 4.0
+    assert builds < 120, builds                  # and hashes lasted longer than two substeps on average
+
+
 def two_blob_scene(sb):
     """Blob A (64x32 lattice) resting on the floor, blob B (48x24) dropped onto it, 300 free
     particles raining in: beams + inter-blob contacts + floor/wall response together."""
