@@ -22,7 +22,7 @@ class WGPUSoftbodyEngineWorker {
     /**
      * @param canvas ignored (kept for signature compatibility; there is no render pass)
      * @param opts {particleRadius, subticks} as in the reference, plus {boundsSize, layout,
-     *        maxParticles, maxBeams, collisionMode, path, tileParticles, device}
+     *        maxParticles, maxBeams, collisionMode, path, tileParticles, device, gridSkin}
      * @param post function(message) receiving {type, data} replies
      */
     constructor(canvas, opts, post) {
@@ -41,7 +41,8 @@ class WGPUSoftbodyEngineWorker {
             boundsSize: this.boundsSize, particleRadius: this.particleRadius, subticks: this.subticks,
             maxParticles: this.bufferMapper.maxParticles, maxBeams: this.bufferMapper.maxBeams, layout: this.layout,
             collisionMode: o.collisionMode !== undefined ? o.collisionMode : COLLIDE.GRID, // same bits as ALLPAIRS
-            path: o.path !== undefined ? o.path : PATH.AUTO, tileParticles: o.tileParticles || 0, device: o.device || 0
+            path: o.path !== undefined ? o.path : PATH.AUTO, tileParticles: o.tileParticles || 0, device: o.device || 0,
+            gridSkin: o.gridSkin || 0
         });
         this.running = true;
         this.visible = true;

@@ -150,6 +150,7 @@ export type NativeEngineOptions = Partial<WGPUSoftbodyEngineOptions> & {
     readonly path?: 0 | 1 | 2           // PATH.AUTO | ATOMIC | TILED
     readonly tileParticles?: number
     readonly device?: number
+    readonly gridSkin?: number          // spatial-hash reuse margin; 0/undefined = adaptive (0.4 r .. 1.6 r), > 0 = fixed
 };
 
 export class WGPUSoftbodyEngine {
