@@ -204,3 +204,39 @@ def test_two_processes_peer_exchange(sb):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "HALO_PEER_OK" in p.stdout
 
+
+def test_halo_and_peer_argument_checks(sb):
+    """The exchange entry points refuse what they cannot honour, with a status and a message (no crash, no
+    silent corruption): odd offsets, use before configuration, segments that do not fit, too many neighbours."""
+    halo = sb.halo
+    buf, plan = halo.slab_scene(sb, 0, 2, 8, 8, depth=2, d=30.0, origin=(100.0, 11.5), jitter=1.0)
+    e = sb.Engine(bounds_size=8000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=0)
+    with pytest.raises(sb.EngineError, match="before sb_write_buffers"):
+        e.halo_configure([0], [1])
+    e.write_buffers(buf)
+    with pytest.raises(sb.EngineError, match="before sb_peer_connect"):
+        e.peer_exchange()
+    gp, sp, gb, sb_ = plan.lists()
+    with pytest.raises(sb.EngineError, match="not active"):
+        e.halo_configure([buf.particle_count + 5], sp)
+    e.halo_configure(gp, sp, gb, sb_)
+    segs, n_send, n_recv, offsets = plan.segments()
+    bad = [o.copy() for o in offsets]
+    bad[0][0] += 1
+    with pytest.raises(sb.EngineError, match="even"):
+        e.halo_set_layout(*bad)
+    e.halo_set_layout(*offsets)
+    box, handle, nbytes = e.peer_mailbox()
+    assert nbytes >= 256 + 8 * n_recv and len(handle) == 64
+    with pytest.raises(sb.EngineError, match="after sb_peer_mailbox"):
+        e.halo_set_layout(*offsets)
+    with pytest.raises(sb.EngineError, match="exceeds the packed send layout"):
+        e.peer_connect([box], [n_recv], [0], [n_send + 2], [0], [0])
+    with pytest.raises(sb.EngineError, match="does not fit"):
+        e.peer_connect([box], [n_send - 2], [0], [n_send], [0], [0])
+    with pytest.raises(sb.EngineError, match="at most"):
+        e.peer_connect([box] * 9, [n_recv] * 9, [0] * 9, [2] * 9, [0] * 9, list(range(9)))
+    e.step(4)
+    e.sync()
+    e.destroy()
+
