@@ -179,6 +179,43 @@ def test_errors_are_loud(sb):
     eng.destroy()
 
 
+@pytest.mark.parametrize("mode,path", [(OFF, TILED), (OFF, ATOMIC), (GRID, TILED), (ALLPAIRS, ATOMIC)])
+def test_empty_and_tiny_scenes(sb, oracle, mode, path):
+    """Edge inputs: no particles at all, one particle, two particles and one beam; frames (substeps + delete
+    pass) and read-back must behave exactly like the oracle."""
+    for n_p, n_b in ((0, 0), (1, 0), (2, 1)):
+        buf = sb.Buffers(1, 8, 8)
+        pts = np.zeros((n_p, 6), "f4")
+        pts[:, 0] = 500.0 + 25.0 * np.arange(n_p)
+        pts[:, 1] = 300.0
+        beams = np.zeros(n_b, sb.layout.BEAM_DTYPE[1])
+        if n_b:
+            beams[0]["a"], beams[0]["b"] = 0, 1
+            for f, v in (("length", 30.0), ("target_length", 30.0), ("last_length", 30.0), ("spring", 50.0), ("damp", 700.0),
+                         ("yield_strain", 0.2), ("strain_break_limit", 0.5)):
+                beams[0][f] = v
+        buf.set_scene(pts, beams)
+        got, exp, _ = run_both(sb, oracle, buf, frames=2, n=3, mode=mode, path=path)
+        assert_same(got, exp, "%d particles %d beams mode %d" % (n_p, n_b, mode))
+        assert got.particle_count == n_p and got.beam_count == n_b
+
+
+def test_v1_layout_at_full_capacity(sb, oracle):
+    """The reference's own limits: 65 536 particles and 65 536 beams behind u16 indices (engineMapping.ts:362-363),
+    every slot in use; 40 substeps with the floor in play, bit-exact."""
+    p, b = sb.scenes.rectangle(40.0, 12.0, 30.0, 256, 256, 50, 700, 0.2, 1e9, anti_diagonal=False, layout=1)
+    b = b[:65536]                                    # the first 65 536 beams in emission order
+    pts = np.zeros((65536, 6), "f4")
+    pts[:, :2] = p
+    pts[:, 3] = -8.0
+    buf = sb.Buffers(1, 65536, 65536)
+    buf.set_scene(pts, b)
+    assert buf.particle_count == 65536 and buf.beam_count == 65536
+    got, exp, info = run_both(sb, oracle, buf, n=40, mode=OFF, path=TILED, bounds=8000.0)
+    assert_same(got, exp, "v1 at capacity")
+    assert (got.particles[:, 1] == 10.0).any()
+
+
 # ---------------------------------------------------------------- spatial hash (SB_COLLIDE_GRID)
 
 @pytest.mark.parametrize("path", [ATOMIC, TILED])
