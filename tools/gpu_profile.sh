@@ -33,6 +33,7 @@ python3 $OLDPWD/bench.py --no-cpu-baseline --width 1000 --height 8000 --mixed-st
 # multi-GPU pieces that one card can show: cost of one ghost refresh (RCCL vs direct peer stores, loopback)
 # and the whole N=2 bench code path with both ranks on this card (rehearsal, not a measurement)
 python3 $OLDPWD/tools/exchange_cost.py 2>/dev/null | grep "^depth" > $OUT/exchange_cost.txt || echo "exchange cost probe failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_exchange -- python3 $OLDPWD/tools/exchange_cost.py > $OUT/trace_exchange.log 2>&1 || echo "exchange trace failed"
 (cd $OLDPWD && python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --rehearse-one-gpu --steps 480 --warmup 48 2>/dev/null | grep "^{" > $OUT/rehearse_2ranks.json) || echo "rehearsal failed"
 (cd $OLDPWD && node softbody-webgpu_amd/host/bench.js > $OUT/node_bench.json 2> $OUT/node_bench.err) || echo "node bench failed"
 find $OUT -name "*.csv" | wc -l

@@ -62,6 +62,10 @@ for name, out in (("exchange_cost.txt", "%s_exchange_cost.txt"), ("rehearse_2ran
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, out % tag))
 
+ke = one("trace_exchange/*/*_kernel_stats.csv")
+if ke:
+    shutil.copy(ke, os.path.join(dst, "%s_exchange_kernel_stats.csv" % tag))
+
 calib = {}
 for which, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
     for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
