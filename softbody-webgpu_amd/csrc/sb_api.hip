@@ -468,6 +468,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.nx_cap = std::max(1u, (uint32_t)std::ceil((double)(x1 - x0) / cell));
         e->grid.ny_cap = std::max(1u, (uint32_t)std::ceil((double)(y1 - y0) / cell));
         e->ncell = e->grid.nx_cap * e->grid.ny_cap; // capacity: the skin only ever makes cells larger than cell_min
+        e->grid.bounds = S;
+        e->grid.wide_side = std::max(1u, (uint32_t)std::floor(std::sqrt((double)e->ncell)));
         const size_t n1 = (size_t)e->ncell + 1;
         SB_TRY(dev_alloc(e, &e->d_cell_cnt, n1));
         SB_HIP(e, hipMemset(e->d_cell_cnt, 0, n1 * 4));
@@ -485,6 +487,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         }
         SB_TRY(dev_alloc(e, &e->d_grid_bar, 1));
         SB_HIP(e, hipMemset(e->d_grid_bar, 0, 4));
+        SB_TRY(dev_alloc(e, &e->d_grid_outside, 2));
+        SB_HIP(e, hipMemset(e->d_grid_outside, 0, 8));
         SbGridCtl ctl[2] = {};
         for (int k = 0; k < 2; k++) {
             ctl[k].force = 1;
@@ -494,6 +498,9 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             ctl[k].cell = cell;
             ctl[k].nx = e->grid.nx_cap;
             ctl[k].ny = e->grid.ny_cap;
+            ctl[k].x0 = x0;
+            ctl[k].y0 = y0;
+            ctl[k].wide = 0;
             const float reach = e->grid.two_r + 2.0f * skin;
             ctl[k].reach2 = reach * reach * 1.001f;
             ctl[k].since = 1000; // "the hash before the first one lasted long": start lean
@@ -754,6 +761,15 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             SB_HIP(e, hipStreamSynchronize(e->stream));
             SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
             *value = ctl.builds;
+        }
+    }
+    else if (k == "grid_wide") { // 1 once the hash switched from the uploaded bounding box to the whole domain
+        *value = 0;
+        if (e->d_grid_ctl) {
+            SbGridCtl ctl;
+            SB_HIP(e, hipStreamSynchronize(e->stream));
+            SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
+            *value = ctl.wide;
         }
     }
     else if (k == "grid_skin_x1000") { // the skin of the current hash, in thousandths of a unit (it adapts)

@@ -447,6 +447,7 @@ struct SbGridBuild {
     float4 *rec;
     uint32_t ncell1_cap;
     uint32_t *bar, *err;
+    uint32_t *outside; // [2], by build parity: particles the build found outside its frame
 };
 
 __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const uint32_t *blk_max, uint32_t nblk,
@@ -506,7 +507,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             skin_new = fmaxf(skin * 0.5f, skin_min);
         }
     }
-    const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new) : geom_in;
+    // the frame: tight until the build before this one found more than 1/64 of the particles outside it
+    const uint32_t wide = geom_in.wide != 0u || (builds > 0u && SB_AGENT_LOAD(&w.outside[(builds - 1u) & 1u]) > P / 64u) ? 1u : 0u;
+    const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new, wide) : geom_in;
     // the common displacement the coming substep is measured against: the mean of the one just done
     float mean_x = tot_x / (float)nblk, mean_y = tot_y / (float)nblk; // one sample particle per workgroup
     if (!(sb_abs(mean_x) < 1.0e30f) || !(sb_abs(mean_y) < 1.0e30f)) mean_x = mean_y = 0.0f;
@@ -520,6 +523,10 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         SB_AGENT_STORE(&cout->reach2, geo.reach2);
         SB_AGENT_STORE(&cout->nx, geo.nx);
         SB_AGENT_STORE(&cout->ny, geo.ny);
+        SB_AGENT_STORE(&cout->x0, geo.x0);
+        SB_AGENT_STORE(&cout->y0, geo.y0);
+        SB_AGENT_STORE(&cout->wide, geo.wide);
+        if (rebuild) SB_AGENT_STORE(&w.outside[(builds + 1u) & 1u], 0u); // the NEXT build's counter (nobody else touches it now)
         SB_AGENT_STORE(&cout->since, rebuild ? 1u : since + 1u);
         SB_AGENT_STORE(&cout->skin_min, skin_min);
         SB_AGENT_STORE(&cout->skin_max, skin_max);
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     // ---- counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
     // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
     // (four particles per thread and round, so that four returning atomics are in flight per lane)
+    uint32_t n_out = 0u;
     for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
         uint32_t c[4], rk[4];
         float2 p[4];
@@ -548,8 +556,13 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             p[u] = i < P ? pos[i] : make_float2(0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            c[u] = sb_grid_coord(p[u].y, g.y0, geo.cell, geo.ny) * geo.nx + sb_grid_coord(p[u].x, g.x0, geo.cell, geo.nx);
+        for (int u = 0; u < 4; u++) {
+            const bool have = i0 + (uint32_t)u * nthreads < P;
+            bool o = false;
+            c[u] = sb_grid_coord_flag(p[u].y, geo.y0, geo.cell, geo.ny, &o) * geo.nx +
+                   sb_grid_coord_flag(p[u].x, geo.x0, geo.cell, geo.nx, &o);
+            n_out += (have && o) ? 1u : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++)
             if (i0 + (uint32_t)u * nthreads < P) rk[u] = atomicAdd(&w.cell_cnt[c[u]], 1u);
@@ -562,6 +575,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             }
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
+    if (n_out && (tid & 63u) == 0u) atomicAdd(&w.outside[builds & 1u], n_out); // one per wave, and only when somebody left the frame
     sb_grid_barrier(w.bar, bar0 + gridDim.x, w.err);
     // ---- exclusive scan of each 8192-cell chunk (1024 threads x 8 cells) + the chunk totals; clears the counts
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -801,7 +817,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
         }();
         const uint32_t blocks = std::min(std::max(work, 1u), max_blocks);
         SbGridBuild gb{e->d_cell_cnt, e->d_cell_scan, e->d_block_off, e->d_rank, e->d_cell_of, e->d_cell_start,
-                       e->d_rec, n, e->d_grid_bar, e->dev_err};
+                       e->d_rec, n, e->d_grid_bar, e->dev_err, e->d_grid_outside};
         k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
                                                             r.pos, e->d_pslot, e->P, e->grid, gb);
         e->grid_par ^= 1u;

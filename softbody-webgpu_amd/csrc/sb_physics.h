@@ -243,9 +243,11 @@ struct SbGrid {
     const uint32_t *cell_start; // per cell (+1 spare entry): absolute index of its first record
     const float4 *rec;          // sorted by cell: {x, y AT BUILD TIME, bits(slot), bits(internal index)}
     const uint32_t *cell_of;    // per particle: its cell at the last build
-    float x0, y0, width, height;
+    float x0, y0, width, height; // the TIGHT frame: the uploaded bounding box plus a margin
     float two_r, cell_min;      // cells are never smaller than cell_min (what the arrays were sized for)
     uint32_t nx_cap, ny_cap;
+    float bounds;               // the WIDE frame is the whole domain [0, bounds]^2, wide_side cells per side at most
+    uint32_t wide_side;         // (what fits the same arrays); used once the scene has left the tight frame
     // neighbour lists (sb_neighbour_list_build): per particle the internal indices of everybody within
     // 2r + 2*skin at build time, in ascending slot order; entry k of particle i at nl[k * nl_stride + i].
     // Written by the particle kernel of the substep that follows a hash build (*fresh != 0: every particle
@@ -286,12 +288,16 @@ struct SbGridCtl {
     // cells and longer lists instead of a rebuild per substep, a quiet one gets them lean again.
     float cell, reach2; // cell width 2r*(1+1/64) + 2*skin (>= cell_min); (2r + 2*skin)^2 with a rounding margin
     uint32_t nx, ny;
+    float x0, y0;       // origin of the frame in use
+    uint32_t wide;      // 0: tight frame; 1: whole domain (more than 1/64 of the particles fell outside the tight one)
     uint32_t since;     // substeps the current hash has served
     float skin_min, skin_max;
 };
 struct SbGridGeom {
     float skin, cell, reach2;
     uint32_t nx, ny;
+    float x0, y0;
+    uint32_t wide;
 };
 #define SB_SCAN_BLOCK 2048u
 #define SB_MAX_WAVES 16
@@ -306,19 +312,34 @@ SB_DEV SbGridGeom sb_grid_geom_load(const SbGridCtl *c)
     m.reach2 = SB_AGENT_LOAD(&c->reach2);
     m.nx = SB_AGENT_LOAD(&c->nx);
     m.ny = SB_AGENT_LOAD(&c->ny);
+    m.x0 = SB_AGENT_LOAD(&c->x0);
+    m.y0 = SB_AGENT_LOAD(&c->y0);
+    m.wide = SB_AGENT_LOAD(&c->wide);
     return m;
 }
 // the geometry that goes with a skin (every workgroup of k_grid_maintain computes the same values)
-SB_DEV SbGridGeom sb_grid_geom_for(const SbGrid &g, float skin)
+SB_DEV SbGridGeom sb_grid_geom_for(const SbGrid &g, float skin, uint32_t wide)
 {
     SbGridGeom m;
     m.skin = skin;
-    m.cell = fmaxf(g.two_r * 1.015625f + 2.0f * skin, g.cell_min);
+    m.wide = wide;
     const float reach = g.two_r + 2.0f * skin;
     m.reach2 = reach * reach * 1.001f;
-    const float fx = ceilf(sb_div(g.width, m.cell)), fy = ceilf(sb_div(g.height, m.cell));
-    m.nx = fx >= 1.0f ? (fx < (float)g.nx_cap ? (uint32_t)fx : g.nx_cap) : 1u; // never more cells than allocated
-    m.ny = fy >= 1.0f ? (fy < (float)g.ny_cap ? (uint32_t)fy : g.ny_cap) : 1u;
+    const float want = g.two_r * 1.015625f + 2.0f * skin;
+    if (wide) { // the whole domain, with cells as coarse as the arrays demand (coarser is slower, never wrong)
+        m.x0 = 0.0f;
+        m.y0 = 0.0f;
+        m.cell = fmaxf(fmaxf(want, g.cell_min), sb_div(g.bounds, (float)g.wide_side));
+        const float f = ceilf(sb_div(g.bounds, m.cell));
+        m.nx = m.ny = f >= 1.0f ? (f < (float)g.wide_side ? (uint32_t)f : g.wide_side) : 1u;
+    } else {
+        m.x0 = g.x0;
+        m.y0 = g.y0;
+        m.cell = fmaxf(want, g.cell_min);
+        const float fx = ceilf(sb_div(g.width, m.cell)), fy = ceilf(sb_div(g.height, m.cell));
+        m.nx = fx >= 1.0f ? (fx < (float)g.nx_cap ? (uint32_t)fx : g.nx_cap) : 1u; // never more cells than allocated
+        m.ny = fy >= 1.0f ? (fy < (float)g.ny_cap ? (uint32_t)fy : g.ny_cap) : 1u;
+    }
     return m;
 }
 
@@ -347,6 +368,21 @@ SB_DEV void sb_store_sample_displacement(uint32_t *blk, uint32_t nblk, float dx,
 {
     SB_AGENT_STORE(&blk[nblk + blockIdx.x], __float_as_uint(sb_abs(dx) < 1.0e30f ? dx : 0.0f));
     SB_AGENT_STORE(&blk[2u * nblk + blockIdx.x], __float_as_uint(sb_abs(dy) < 1.0e30f ? dy : 0.0f));
+}
+
+// cell coordinate with the clamp made visible: *outside is set when a FINITE coordinate had to be clamped
+SB_DEV uint32_t sb_grid_coord_flag(float x, float x0, float cell, uint32_t n, bool *outside)
+{
+    float q = sb_div(x - x0, cell);
+    if (!(q > 0.0f)) {
+        if (q < 0.0f) *outside = true; // (zero and NaN are not "outside")
+        return 0u;
+    }
+    if (q >= (float)n) {
+        if (q < 1.0e30f) *outside = true;
+        return n - 1u;
+    }
+    return (uint32_t)q;
 }
 
 SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)

@@ -314,6 +314,54 @@ def test_grid_fast_gas_adapts_its_skin(sb, oracle, path):
     assert builds < 120, builds                  # and hashes lasted longer than two substeps on average
 
 
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_follows_a_scene_that_leaves_its_frame(sb, oracle, path):
+    """The hash is framed on the uploaded bounding box plus a margin.  Two small blobs and a sheet of rain thrown
+    down at 120 units/s from the top of a 6000 box leave that frame within a few frames; the hash must notice (it
+    counts the particles it had to clamp) and re-frame on the whole domain, not pile everybody into its edge
+    cells.  Bits of the all-pairs scan throughout, the blobs' mid-air collision included."""
+    buf = leaving_scene(sb)
+    eng = sb.Engine(bounds_size=6000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                    collision_mode=GRID, path=path, tile_particles=64)
+    ref = oracle.OracleEngine(6000.0, 10.0, 64, 2, ALLPAIRS, threads=8)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    assert eng.info("grid_wide") == 0
+    for frame in range(45):
+        eng.frame()
+        ref.frame()
+        if frame in (5, 20):
+            assert_same(eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy()), "frame %d" % frame)
+    got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+    wide = eng.info("grid_wide")
+    eng.destroy()
+    assert np.isfinite(exp.particles).all()
+    assert_same(got, exp, "leaving the frame, path %d" % path)
+    assert exp.particles[:exp.particle_count, 1].max() < 4500.0    # everybody is below the tight frame (it ended near y = 4750)
+    assert wide == 1
+
+
+def leaving_scene(sb):
+    parts, beams, base = [], [], 0
+    for ox, vx in ((900.0, 15.0), (1500.0, -15.0)):
+        p, b = sb.scenes.rectangle(ox, 5200.0, 30.0, 10, 8, 50, 700, 0.2, 1e9, base=base, anti_diagonal=True, layout=2)
+        pv = np.zeros((p.shape[0], 6), "f4")
+        pv[:, :2] = p
+        pv[:, 2], pv[:, 3] = vx, -120.0
+        parts.append(pv)
+        beams.append(b)
+        base += p.shape[0]
+    k = np.arange(125)
+    rain = np.zeros((125, 6), "f4")
+    rain[:, 0] = 850.0 + 40.0 * (k % 25)
+    rain[:, 1] = 5600.0 + 40.0 * (k // 25)
+    rain[:, 3] = -130.0
+    parts.append(rain)
+    buf = sb.Buffers(2, base + 125, sum(b.shape[0] for b in beams))
+    buf.set_scene(np.concatenate(parts), np.concatenate(beams))
+    return buf
+
+
 def two_blob_scene(sb):
     """Blob A (64x32 lattice) resting on the floor, blob B (48x24) dropped onto it, 300 free
     particles raining in: beams + inter-blob contacts + floor/wall response together."""
