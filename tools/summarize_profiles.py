@@ -13,6 +13,9 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
+if not os.path.isdir(src) or not glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    sys.exit("%s holds no profile run (tools/gpu_profile.sh %s did not run or did not finish): nothing summarised, "
+             "profiles/ left as it is" % (src, tag))
 os.makedirs(dst, exist_ok=True)
 
 
