@@ -7,14 +7,17 @@ Workload at N=1: BASELINE config 2 -- one 1000x1000 lattice blob, 1 000 000 part
 resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 1000 --warmup 64
+    python bench.py --gpus N ...          (starts N ranks itself, as child processes, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline`, `cpu_baseline` and, at N=1, `extra`
+(BASELINE config 3 measured in the same run, upload / read-back times).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,9 +38,12 @@ def parse():
     ap.add_argument("--spacing", type=float, default=30.0, help="lattice spacing d (particle radius is 10)")
     ap.add_argument("--origin-y", type=float, default=1000.0, help="y of the lattice's bottom row (10 = resting on the floor)")
     ap.add_argument("--config3", action="store_true",
-                    help="BASELINE config 3 on a lattice: 4000x250 at spacing 22 resting on the floor (floor response "
-                         "active, 8 collision candidates per particle in reach of the lists; the lattice does not "
-                         "get closer than 2r in the timed window -- see --soup for contacts that fire)")
+                    help="BASELINE config 3 as the main workload: the blob pile of scenes.config3_buffers (lattice blobs "
+                         "resting on the floor and on each other, ~1 M particles, spatial-hash collisions); without this "
+                         "flag the same scene is measured after the main workload and reported under `extra`")
+    ap.add_argument("--lattice-on-floor", action="store_true",
+                    help="round 1's config-3 stand-in: a 4000x250 lattice at spacing 22 resting on the floor (floor "
+                         "response and 8 collision candidates per particle, but no pair closer than 2r in the window)")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ghost-depth", type=int, default=24,
@@ -60,11 +66,53 @@ def parse():
                     help="N>1 on a single-GPU box: every rank uses cuda:0 and the process group is gloo (control "
                          "plane only), so the multi-rank code path and the peer exchange can be exercised; not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 record of `extra`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
 
 
-def cpu_baseline(sb, buf, bounds, mode, budget_s, subticks=64):
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not
+    touched the GPU and never will), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in child.stdout:
+        if line.startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the ranks printed %d result lines, expected 1\n" % lines)
+        rc = 1
+    return rc
+
+
+def oracle_rate(orc, buf, bounds, mode, threads, budget_s, subticks):
+    """particle-steps/s of the oracle on `buf` for about budget_s seconds (at least 2 substeps)."""
+    ref = orc.OracleEngine(bounds, 10.0, subticks, buf.layout, mode, threads=threads)
+    ref.write_buffers(buf)
+    t0 = time.perf_counter()
+    ref.step(2)
+    per = (time.perf_counter() - t0) / 2
+    n = max(2, min(2000, int(budget_s / max(per, 1e-6)) // 2 * 2))
+    t0 = time.perf_counter()
+    ref.step(n)
+    dt = time.perf_counter() - t0
+    return dict(value=buf.particle_count * n / dt, substeps=n, seconds=dt, threads=threads)
+
+
+def cpu_baseline(buf, bounds, mode, budget_s, subticks=64):
     """Times the oracle (our C restatement of compute.wgsl; the reference has no CPU path) on
     the same scene for a bounded number of substeps.  Reported beside the GPU, never the target."""
     import __graft_entry__ as ge
@@ -72,28 +120,35 @@ def cpu_baseline(sb, buf, bounds, mode, budget_s, subticks=64):
     orc.build()
     # the GPU box grants about 16 cores per GPU; more OpenMP threads than that only thrash
     cores = min(16, len(os.sched_getaffinity(0)))
-    P = buf.particle_count
-    out = {}
-    for label, threads, share in (("single", 1, 0.35), ("all", cores, 0.65)):
-        ref = orc.OracleEngine(bounds, 10.0, subticks, buf.layout, mode, threads=threads)
-        ref.write_buffers(buf)
-        t0 = time.perf_counter()
-        ref.step(2)
-        per = (time.perf_counter() - t0) / 2
-        n = max(2, min(2000, int(budget_s * share / max(per, 1e-6)) // 2 * 2))
-        t0 = time.perf_counter()
-        ref.step(n)
-        dt = time.perf_counter() - t0
-        out[label] = dict(value=P * n / dt, substeps=n, seconds=dt, threads=threads)
+    one = oracle_rate(orc, buf, bounds, mode, 1, budget_s * 0.35, subticks)
+    al = oracle_rate(orc, buf, bounds, mode, cores, budget_s * 0.65, subticks)
     return {
-        "value": out["all"]["value"], "unit": "particle-steps/s", "cores": out["all"]["threads"],
-        "kind": "port",
+        "value": al["value"], "unit": "particle-steps/s", "cores": al["threads"], "kind": "port",
         "sample": "oracle/sb_oracle.c (C restatement of compute.wgsl; the reference has no CPU path), same "
                   "scene, %d substeps in %.1f s with %d OpenMP threads; 1 thread: %.3g particle-steps/s over %d substeps"
-                  % (out["all"]["substeps"], out["all"]["seconds"], out["all"]["threads"],
-                     out["single"]["value"], out["single"]["substeps"]),
-        "single_thread_value": out["single"]["value"],
+                  % (al["substeps"], al["seconds"], al["threads"], one["value"], one["substeps"]),
+        "single_thread_value": one["value"],
     }
+
+
+def cpu_baseline_config3(sb, buf, bounds, budget_s):
+    """BASELINE.md 3, rows "cfg 3 CPU": the oracle's spatial-hash mode on the config-3 scene (1 thread, all
+    cores) and the reference's own all-pairs scan (compute.wgsl:142-170) at its own limit of 65 536 particles."""
+    import __graft_entry__ as ge
+    orc = ge.load_oracle()
+    orc.build()
+    cores = min(16, len(os.sched_getaffinity(0)))
+    g1 = oracle_rate(orc, buf, bounds, orc.COLLIDE_GRID, 1, budget_s * 0.25, 64)
+    gn = oracle_rate(orc, buf, bounds, orc.COLLIDE_GRID, cores, budget_s * 0.4, 64)
+    small, sbounds = sb.scenes.config3_buffers(65536)
+    ap = oracle_rate(orc, small, sbounds, orc.COLLIDE_ALLPAIRS, cores, budget_s * 0.35, 64)
+    return {"kind": "port", "unit": "particle-steps/s", "cores": cores,
+            "grid_1M_all_cores": gn["value"], "grid_1M_one_thread": g1["value"],
+            "allpairs_65536_all_cores": ap["value"],
+            "sample": "oracle grid mode on the same %d-particle pile: %d substeps / %.1f s on %d threads, %d substeps / %.1f s "
+                      "on 1 thread; oracle all-pairs (the reference's O(P^2) scan) on a %d-particle pile: %d substeps / %.1f s "
+                      "on %d threads" % (buf.particle_count, gn["substeps"], gn["seconds"], cores, g1["substeps"], g1["seconds"],
+                                         small.particle_count, ap["substeps"], ap["seconds"], cores)}
 
 
 def committed_traffic(workload, kernel):
@@ -176,15 +231,80 @@ def peer_exchanger(halo, eng, plan, buf, dist, torch, ctl):
     return ex if ok else None
 
 
+def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
+    """`achieved` = the launched kernels' own compulsory HBM bytes per substep (sb_get_info "substep_hbm_bytes":
+    every array element the substep has to read or write with the data layout the engine holds) / HIP-event time
+    per substep; a fraction of the 8 TB/s peak that is <= 1 by construction and that the PMC bytes under `traffic`
+    must reproduce.  The reference-layout figure of SURVEY.md 8(d) (52 B per beam + 48 B per particle) is reported
+    beside it as an equivalent rate, clearly not a fraction: this kernel does not move those bytes."""
+    per_substep_s = kernel_ms * 1e-3 / steps
+    own = float(eng.info("substep_hbm_bytes"))
+    k = max(1, eng.info("substeps_per_launch"))
+    ach = own / per_substep_s / 1e9
+    tiled = eng.info("path") == 2
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": eng.kernel_name() if tiled else "k_beams_atomic+k_particles",
+            "substeps_per_launch": k, "avg_launch_us": per_substep_s * k * 1e6,
+            "compulsory_bytes_per_launch": own * k,
+            "reference_layout_bytes_per_substep": 52.0 * B_local + 48.0 * P_local,
+            "reference_layout_equiv_GBps": (52.0 * B_local + 48.0 * P_local) / per_substep_s / 1e9,
+            "note": "achieved = compulsory bytes of the launched kernel (engine's own data layout: %d beam copies for %d "
+                    "beams, material mode %d) / HIP-event time of the timed region; reference_layout_equiv_GBps = "
+                    "(52*B + 48*P) / the same time is what a kernel streaming the reference's records would need to "
+                    "sustain for this step rate -- an equivalence, not a fraction of the roof"
+                    % (eng.info("beam_copies"), B_local, eng.info("material_mode"))}
+    tr = committed_traffic(workload, roof["kernel"].split("<")[0])
+    if tr:
+        roof["traffic"] = tr[0]
+        roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
+        roof["traffic_over_compulsory"] = tr[0] / (own * k)
+    return roof
+
+
+def measure_config3(sb, a):
+    """BASELINE config 3 in the same run (rank 0, N=1): the blob pile, spatial-hash collisions, same step counts."""
+    import numpy as np
+    buf, bounds = sb.scenes.config3_buffers()
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=64, layout=2, max_particles=buf.max_particles,
+                    max_beams=buf.max_beams, collision_mode=2, grid_skin=a.grid_skin)
+    t0 = time.perf_counter()
+    eng.write_buffers(buf)
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(sb.scenes.CONFIG3_SETTLE_FRAMES):   # the pile comes to rest on itself (untimed; delete passes included)
+        eng.frame()
+    eng.sync()
+    settled = eng.load_buffers(buf.copy())              # what the CPU baseline below starts from, too
+    builds0 = eng.info("grid_builds")
+    eng.step(a.warmup)
+    eng.sync()
+    ms = eng.step_timed(a.steps)
+    eng.sync()
+    builds = eng.info("grid_builds") - builds0
+    out = eng.load_buffers(buf.copy())
+    eng.destroy()
+    P = buf.particle_count
+    v = np.hypot(out.particles[:P, 2], out.particles[:P, 3])
+    rec = {"workload": sb.scenes.CONFIG3_TEXT % (P, buf.beam_count, bounds),
+           "value": P * a.steps / (ms * 1e-3), "unit": "particle-steps/s", "us_per_substep": ms * 1e3 / a.steps,
+           "steps": a.steps, "warmup": a.warmup, "grid_builds": builds, "upload_ms": upload_ms,
+           "finite": bool(np.isfinite(out.particles[:P]).all()), "max_speed": float(v.max()),
+           "beams_left": out.beam_count,
+           "contacts": "tools/config3_contacts_check.py measures the share of particles the collision loop changes "
+                       "(profiles/r02_config3_contacts_check.txt)"}
+    if not a.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline_config3(sb, settled, bounds, a.cpu_seconds)
+    return rec
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world
     import torch
     import __graft_entry__ as ge
     sb = ge.load_package()
@@ -206,7 +326,7 @@ def main():
     from importlib import import_module
     halo = import_module("softbody_webgpu_amd.halo") if world > 1 else None
 
-    if a.config3:
+    if a.lattice_on_floor:
         a.width, a.height, a.spacing, a.origin_y, a.collisions = 4000, 250, 22.0, 10.0, "grid"
     if a.soup:
         a.collisions = "grid"
@@ -214,16 +334,21 @@ def main():
             a.spacing = 40.0
         if a.origin_y == 1000.0:
             a.origin_y = 30.0       # bottom rows within reach of the floor
+    if a.config3:
+        a.collisions = "grid"
     W, H = a.width, a.height
     d = a.spacing
     mode = {"off": 0, "grid": 2}[a.collisions]
     path = {"auto": 0, "atomic": 1, "tiled": 2}[a.path]
     # global scene: N slabs of W columns side by side (weak scaling: per-GPU work is fixed)
     bounds = float(max(W * world, H) * d + 2000.0)
-    if a.soup:
+    if a.soup or a.config3:
         if world != 1:
-            sys.exit("--soup is a single-GPU scene")
-        buf = sb.scenes.soup_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=10.0, speed=a.soup_speed)
+            sys.exit("--soup / --config3 are single-GPU scenes")
+        if a.soup:
+            buf = sb.scenes.soup_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=10.0, speed=a.soup_speed)
+        else:
+            buf, bounds = sb.scenes.config3_buffers()
         plan = None
     elif world == 1:
         buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0, layout=2)
@@ -241,7 +366,9 @@ def main():
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
                     path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin)
+    t0 = time.perf_counter()
     eng.write_buffers(buf)
+    upload_ms = (time.perf_counter() - t0) * 1e3
     exchange_mode = None
     if plan is None:
         stepper = eng.step
@@ -292,38 +419,19 @@ def main():
             workload = ("BASELINE config 3 as a particle soup: %dx%d FREE particles (no beams) on a grid of %g jittered "
                         "by +-10, velocities up to %g units/s, gravity, floor and walls, spatial-hash collisions, "
                         "subticks %d, v2 (u32) layout" % (W, H, d, a.soup_speed, a.subticks))
+        elif a.config3:
+            workload = sb.scenes.CONFIG3_TEXT % (P_local, B_local, bounds)
         else:
             placed = "" if (d == 30.0 and a.origin_y == 1000.0) else ", spacing %g, bottom row at y=%g" % (d, a.origin_y)
-            if a.config3:
+            if a.lattice_on_floor:
                 placed += " (resting on the floor: floor response active, 8 collision candidates per particle tested " \
                           "every substep, none closer than 2r in the timed window)"
             workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
                         "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
-                        % ("3" if a.config3 else "2", W, H, P_local, B_local,
+                        % ("3" if mode == 2 else "2", W, H, P_local, B_local,
                            "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else "spring 50 damp 700",
                            a.subticks, a.collisions, placed))
-        copies = eng.info("beam_copies")
-        alg_bytes = 52.0 * B_local + 48.0 * P_local  # per substep, one launch
-        roof = None
-        if kernel_ms is not None:
-            per_launch_s = kernel_ms * 1e-3 / a.steps
-            ach = alg_bytes / per_launch_s / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_substep_tiled" if eng.info("path") == 2 else "k_beams_atomic+k_particles",
-                    "avg_launch_us": per_launch_s * 1e6,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "achieved = (52*B + 48*P) bytes / (HIP-event time of the timed region / steps); "
-                            "beam copies on device: %d for %d beams" % (copies, B_local)}
-        if roof is not None:
-            tr = committed_traffic(workload, roof["kernel"])
-            if tr:
-                roof["traffic"] = tr[0]
-                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
-                # the kernel moves far fewer bytes than the algorithmic figure (dictionary-coded beam
-                # parameters, outputs stored lazily, zero accelerations skipped): say how busy HBM really is
-                roof["physical_GBps"] = tr[0] / (roof["avg_launch_us"] * 1e-6) / 1e9
-                roof["physical_frac"] = roof["physical_GBps"] / HBM_PEAK_GBS
+        roof = roofline(eng, kernel_ms, a.steps, P_local, B_local, workload) if kernel_ms is not None else None
         line = {
             "metric": "particle-steps/sec", "value": P_total * a.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
@@ -339,12 +447,22 @@ def main():
                           exchange_mode or "RCCL neighbour send/recv, " + transport.mode)},
             "roofline": roof,
         }
+        if world == 1:
+            t0 = time.perf_counter()
+            eng.load_buffers(buf.copy())
+            readback_ms = (time.perf_counter() - t0) * 1e3
+            line["extra"] = {"upload_ms": upload_ms, "readback_ms": readback_ms,
+                             "upload_note": "sb_write_buffers / sb_load_buffers of the whole scene, host buffers <-> HBM, "
+                                            "tiling and AoS<->SoA transposes included; never part of `value`"}
+    eng.destroy()
+    if rank == 0:
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(sb, buf, bounds, mode, a.cpu_seconds, a.subticks)
+            line["cpu_baseline"] = cpu_baseline(buf, bounds, mode, a.cpu_seconds, a.subticks)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not a.no_extra and not (a.config3 or a.soup):
+            line["extra"]["config3"] = measure_config3(sb, a)
         print(json.dumps(line), flush=True)
-    eng.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -149,7 +149,9 @@ sb_status sb_load_buffers(sb_engine *e, void *metadata, size_t metadata_bytes,
 sb_status sb_get_counts(sb_engine *e, uint32_t *particles, uint32_t *beams);
 
 /* introspection for benches/tests: key = "path", "tiles", "beam_copies", "halo_particles",
- * "device_bytes", "substeps_done", "kernels_per_substep". */
+ * "device_bytes", "substeps_done", "kernels_per_substep", "substep_hbm_bytes" (the HBM bytes one substep
+ * launch has to move with the data layout the engine holds: the launched kernel's own compulsory traffic),
+ * "grid_cells", "grid_builds", "grid_wide", "grid_skin_x1000", "material_mode", "materials", "local_index_bits". */
 sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value);
 
 /* ---- multi-GPU halo exchange; one engine per rank/GPU, each holding its

@@ -740,11 +740,32 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
     return SB_OK;
 }
 
+// HBM bytes ONE lean substep launch has to move with the data layout this engine actually holds (the launched
+// kernel's own compulsory traffic: what bench.py prices `roofline.achieved` with, and what the PMC counters
+// of profiles/ must reproduce).  Counted: every array element the kernel reads or writes once per substep.
+// Not counted: accelerations (skipped while they are zero), strain/stress (stored by the last
+// substep of a call only), target stores (plastic yield only), neighbour-list traffic of SB_COLLIDE_GRID.
+static uint64_t substep_bytes_model(const sb_engine *e)
+{
+    const uint64_t P = e->P, nc = e->nbeam;
+    if (e->path == SB_PATH_TILED) {
+        uint64_t per_copy = 4 /* endpoint word */ + 4 /* target */ + 4 + 4 /* last: read, written */;
+        if (e->mat_mode <= 1) per_copy += 4;  // per-copy rest length
+        if (e->mat_mode == 0) per_copy += 16; // per-copy spring, damp, yield, limit
+        return nc * per_copy + P * 32 /* pos, vel: read and written */ + (uint64_t)e->nhalo * 12 /* index + position */ +
+               (uint64_t)e->ntiles * (3 * 4 + 2 * 4) /* tile tables, acceleration flags */ + (uint64_t)e->nmat * 24;
+    }
+    // atomic path: the reference's own schedule (compute.wgsl:98,125: whole records in and out, 4 atomics per beam)
+    return nc * (8 + 36 + 16 + 16 + 16) + P * (48 + 16);
+}
+
 sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
 {
     if (!e || !key || !value) return SB_ERR_INVALID;
     std::string k(key);
     if (k == "path") *value = e->path;
+    else if (k == "substep_hbm_bytes") *value = substep_bytes_model(e);
+    else if (k == "substeps_per_launch") *value = 1;
     else if (k == "tiles") *value = e->ntiles;
     else if (k == "beam_copies") *value = e->nbeam;
     else if (k == "halo_particles") *value = e->nhalo;

@@ -105,7 +105,7 @@ struct sb_engine {
     SbGridCtl *d_grid_ctl = nullptr;  // [2] rebuild decision state by substep parity (device resident: no host sync per substep)
     uint32_t *d_blk_max[2] = {};      // per workgroup of the particle kernel: largest displacement (float bits), by parity
     uint32_t *d_nl_count = nullptr, *d_nl = nullptr; // neighbour lists (SbGrid)
-    uint32_t *d_grid_outside = nullptr; // [2] particles outside the hash's frame, by build parity
+    uint32_t *d_grid_outside = nullptr; // particles the hash build in progress found outside its frame (zero between builds)
     uint32_t *d_grid_bar = nullptr;   // arrival counter of k_grid_maintain's device-wide barrier
     uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
     uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)

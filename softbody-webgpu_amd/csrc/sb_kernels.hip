@@ -447,7 +447,7 @@ struct SbGridBuild {
     float4 *rec;
     uint32_t ncell1_cap;
     uint32_t *bar, *err;
-    uint32_t *outside; // [2], by build parity: particles the build found outside its frame
+    uint32_t *outside; // particles the build in progress found outside its frame (zero between builds)
 };
 
 __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const uint32_t *blk_max, uint32_t nblk,
@@ -507,8 +507,10 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             skin_new = fmaxf(skin * 0.5f, skin_min);
         }
     }
-    // the frame: tight until the build before this one found more than 1/64 of the particles outside it
-    const uint32_t wide = geom_in.wide != 0u || (builds > 0u && SB_AGENT_LOAD(&w.outside[(builds - 1u) & 1u]) > P / 64u) ? 1u : 0u;
+    // the frame: tight until the build before this one found more than 1/64 of the particles outside it (that build's
+    // block 0 published the verdict in wide_next; every workgroup of this launch reads the same word)
+    const uint32_t wide_next_in = SB_AGENT_LOAD(&cin->wide_next);
+    const uint32_t wide = (geom_in.wide != 0u || wide_next_in != 0u) ? 1u : 0u;
     const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new, wide) : geom_in;
     // the common displacement the coming substep is measured against: the mean of the one just done
     float mean_x = tot_x / (float)nblk, mean_y = tot_y / (float)nblk; // one sample particle per workgroup
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         SB_AGENT_STORE(&cout->x0, geo.x0);
         SB_AGENT_STORE(&cout->y0, geo.y0);
         SB_AGENT_STORE(&cout->wide, geo.wide);
-        if (rebuild) SB_AGENT_STORE(&w.outside[(builds + 1u) & 1u], 0u); // the NEXT build's counter (nobody else touches it now)
+        if (!rebuild) SB_AGENT_STORE(&cout->wide_next, wide_next_in); // (a build publishes its own verdict after its count phase)
         SB_AGENT_STORE(&cout->since, rebuild ? 1u : since + 1u);
         SB_AGENT_STORE(&cout->skin_min, skin_min);
         SB_AGENT_STORE(&cout->skin_max, skin_max);
@@ -577,8 +579,15 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
-    if (n_out && (tid & 63u) == 0u) atomicAdd(&w.outside[builds & 1u], n_out); // one per wave, and only when somebody left the frame
+    if (n_out && (tid & 63u) == 0u) atomicAdd(w.outside, n_out); // one per wave, and only when somebody left the frame
     sb_grid_barrier(w.bar, bar0 + gridDim.x, w.err);
+    // every workgroup's count is in: ONE thread reads the total, publishes the verdict for the next build and re-zeroes the
+    // counter (nobody touches it again before the count phase of the next build, a later launch)
+    if (blockIdx.x == 0 && tid == 0) {
+        const uint32_t total = __hip_atomic_load(w.outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SB_AGENT_STORE(&ctl[par ^ 1u].wide_next, (wide != 0u || total > P / 64u) ? 1u : 0u);
+        SB_AGENT_STORE(w.outside, 0u);
+    }
     // ---- exclusive scan of each 8192-cell chunk (1024 threads x 8 cells) + the chunk totals; clears the counts
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t base = chunk * SB_MT_CHUNK + tid * 8u;

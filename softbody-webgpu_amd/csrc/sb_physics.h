@@ -51,6 +51,32 @@ SB_DEV float sb_div(float a, float b) { return a / b; }
 #endif
 SB_DEV float sb_length(float x, float y) { return sb_sqrt(x * x + y * y); }
 
+// ---------------------------------------------------------------- short correctly rounded sqrt / reciprocal
+// The IEEE sequences the compiler emits cost ~15 (sqrt: range scaling, v_sqrt_f32, two neighbour residuals,
+// class fix-up) and ~11 (1/x: v_div_scale x2, v_rcp_f32, five fmas, v_div_fmas, v_div_fixup) instructions, about a
+// quarter of the arithmetic of a beam.  Away from the ends of the exponent range much shorter sequences return the
+// same bits; "the same bits" is not an estimate: tools/exact_math_check.hip runs every one of the 2^32 binary32
+// inputs through both on the GPU (gfx950: 1 509 949 441 inputs in the sqrt gate, 754 974 721 in the reciprocal
+// gate, 0 mismatches each; the log is profiles/r02_exact_math_check.txt).
+//   sqrt: y = v_rsq_f32(x); g = x*y; h = y/2; g' = fma(fma(-g, g, x), h, g)        2^-90 <= x <= 2^90
+//   1/x : y = v_rcp_f32(x); y' = fma(y, fma(-x, y, 1), y)                          2^-45 <= x <= 2^45
+// (the reciprocal gate holds every sqrt the sqrt gate can return).  Callers test the gate for the whole wave and take
+// the IEEE sequences otherwise, so zero, subnormal, huge, infinite and NaN operands never reach the short forms.
+SB_DEV bool sb_in_sqrt_gate(float x) { return x >= 0x1p-90f && x <= 0x1p90f; } // false for NaN
+SB_DEV float sb_sqrt_gated(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
+SB_DEV float sb_rcp_gated(float x)
+{
+    const float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+}
+// true when EVERY active lane of the wave is inside the gate (one s_cmp on the ballot: the branch is wave-uniform)
+SB_DEV bool sb_wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+
 // i32(f): truncate toward zero, saturating, NaN -> 0 (compute.wgsl:127-130).  That is exactly what
 // one v_cvt_i32_f32 does on gfx950 (out-of-range clamps to INT_MIN/INT_MAX, NaN gives 0); spelled as
 // inline asm so neither a chain of range checks nor a UB-exploiting fold of `(int)x` can appear.
@@ -174,13 +200,20 @@ SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float inv_l
     const float beam_stress_scale = 1.0f / 20.0f; // :71
     SbBeamResult r;
     float dx = pb.x - pa.x, dy = pb.y - pa.y; // :103
-    const float len0 = sb_length(dx, dy);     // :104 / :108 (same value unless the guard fires)
-    const bool degenerate = len0 == 0.0f;     // :104-107
-    dx = degenerate ? 0.0f : dx;
-    dy = degenerate ? -1.0e-10f : dy;
-    const float len = degenerate ? sb_length(0.0f, -1.0e-10f) : len0; // constant folded, correctly rounded
+    const float len2 = dx * dx + dy * dy;
+    float len, inv_len;
+    if (sb_wave_all(sb_in_sqrt_gate(len2))) { // every beam of the wave has an ordinary length: short exact forms
+        len = sb_sqrt_gated(len2);            // :108 (the guard of :104 cannot fire: len2 >= 2^-90)
+        inv_len = sb_rcp_gated(len);
+    } else {
+        const float len0 = sb_sqrt(len2);     // :104 / :108 (same value unless the guard fires)
+        const bool degenerate = len0 == 0.0f; // :104-107
+        dx = degenerate ? 0.0f : dx;
+        dy = degenerate ? -1.0e-10f : dy;
+        len = degenerate ? sb_length(0.0f, -1.0e-10f) : len0; // constant folded, correctly rounded
+        inv_len = sb_div(1.0f, len);
+    }
     const float force_mag = (target_length - len) * spring + (last_length - len) * damp; // :110
-    const float inv_len = sb_div(1.0f, len);
     const float nx = dx * inv_len, ny = dy * inv_len;     // normalize(diff) = diff * (1 / length(diff)), DESIGN.md 2
     const float fx = force_mag * nx, fy = force_mag * ny; // :111
     const float strain = (len - target_length) * inv_length; // :112, x / y pinned as x * (1 / y)
@@ -292,6 +325,9 @@ struct SbGridCtl {
     uint32_t wide;      // 0: tight frame; 1: whole domain (more than 1/64 of the particles fell outside the tight one)
     uint32_t since;     // substeps the current hash has served
     float skin_min, skin_max;
+    uint32_t wide_next; // 1: the last build counted more than 1/64 of the particles outside its frame, so the NEXT build
+                        //    frames the whole domain.  Written by ONE thread (block 0, after the build's first device-wide
+                        //    barrier) and read by every workgroup of a LATER launch: the decision has a single source.
 };
 struct SbGridGeom {
     float skin, cell, reach2;
@@ -586,9 +622,16 @@ SB_DEV void sb_particle_finish(const SbParams &prm, const SbConsts &c, SbParticl
     const float particle_force_scale = 65536.0f;
     particle.a.x += c.gravity_x; // :172
     particle.a.y += c.gravity_y;
-    float vl = sb_length(particle.v.x, particle.v.y);
+    const float v2 = particle.v.x * particle.v.x + particle.v.y * particle.v.y;
+    float vl, inv_vl = 0.0f;
+    if (sb_wave_all(sb_in_sqrt_gate(v2) || v2 == 0.0f)) { // (a particle at rest has no drag: nothing to take a root of)
+        vl = v2 == 0.0f ? 0.0f : sb_sqrt_gated(v2);
+        inv_vl = sb_rcp_gated(vl); // unused (infinite) at rest
+    } else {
+        vl = sb_sqrt(v2);
+        if (vl > 0.0f) inv_vl = sb_div(1.0f, vl);
+    }
     if (vl > 0.0f) { // :174-176
-        const float inv_vl = sb_div(1.0f, vl);
         float nx = particle.v.x * inv_vl, ny = particle.v.y * inv_vl;
         float px = sb_pow(sb_abs(particle.v.x), c.drag_exp);
         float py = sb_pow(sb_abs(particle.v.y), c.drag_exp);

@@ -132,6 +132,7 @@ class Engine:
             self._h = None
             raise EngineError(st, L.sb_last_error(None).decode())
         self.layout, self.max_particles, self.max_beams = layout, max_particles, max_beams
+        self.collision_mode = collision_mode
         self.subticks = (subticks + 1) // 2 * 2
 
     def _check(self, st):
@@ -200,6 +201,13 @@ class Engine:
         v = ctypes.c_uint64()
         self._check(load_library().sb_get_info(self._h, key.encode(), ctypes.byref(v)))
         return v.value
+
+    def kernel_name(self):
+        """Name (up to the template arguments) of the kernel that does the substeps of this engine, as rocprofv3
+        lists it."""
+        if self.info("path") != PATH_TILED:
+            return "k_beams_atomic+k_particles"
+        return "k_substep_tiled_grid" if self.collision_mode == COLLIDE_GRID else "k_substep_tiled"
 
     def sync_quiet(self):
         """sync() that swallows a reported device-side timeout (used when abandoning a failed exchange set-up)."""

@@ -147,3 +147,53 @@ def mix_stiffness(buf, seed=1, subticks=128):
     buf.beams["spring"][:B] = springs
     buf.beams["damp"][:B] = damps
     return buf
+
+
+def blob_pile_buffers(columns, layers, bw=9, bh=4, d=30.0, gap=21.0, spring=50.0, damp=700.0,
+                      yield_strain=0.2, strain_limit=0.5, bounds=None, layout=LAYOUT_V2, seed=1):
+    """BASELINE config 3 as the reference's own scene does it (main.ts:218-224: lattice blobs resting on the
+    floor and on each other): `layers` courses of `columns` blobs, each a bw x bh `addRectangle` lattice with
+    the material of main.ts:220 (spring 50, damp 700, yield 0.2, limit 0.5), laid like bricks (every other
+    course shifted by half a blob) with `gap` between the particle centres of neighbouring blobs (2r = 20 is
+    touching), the bottom course on the floor.  Beams, resting contacts and the floor response all act in
+    steady state.  Returns (Buffers, bounds_size)."""
+    bwid, bhei = (bw - 1) * float(d), (bh - 1) * float(d)
+    pitch_x, pitch_y = bwid + gap, bhei + gap
+    parts, beams, base = [], [], 0
+    x_left = 10.0 + 0.5 * pitch_x
+    for L in range(layers):
+        shift = 0.0 if L % 2 == 0 else 0.5 * pitch_x
+        for c in range(columns):
+            p, b = rectangle(x_left + shift + c * pitch_x, 10.0 + L * pitch_y, d, bw, bh, spring, damp,
+                             yield_strain, strain_limit, base=base, anti_diagonal=True, layout=layout)
+            parts.append(p)
+            beams.append(b)
+            base += p.shape[0]
+    p = np.concatenate(parts)
+    pv = np.zeros((p.shape[0], 6), dtype="<f4")
+    pv[:, :2] = p
+    b = np.concatenate(beams)
+    need = float(max(x_left + (columns + 0.5) * pitch_x + 10.0, layers * pitch_y + 1000.0))
+    S = float(bounds) if bounds else need
+    if S < need:
+        raise ValueError("blob pile needs a box of %g, got %g" % (need, S))
+    buf = Buffers(layout, pv.shape[0], b.shape[0])
+    buf.set_scene(pv, b)
+    return buf, S
+
+
+CONFIG3_SETTLE_FRAMES = 48
+CONFIG3_TEXT = ("BASELINE config 3: %d particles / %d beams as a pile of 9x4 lattice blobs (the reference's own blob, "
+                "main.ts:220: spacing 30, spring 50, damp 700, yield 0.2, break limit 0.5) laid like bricks, touching, "
+                "courses resting on the floor and on each other in a %g box; gravity, floor, walls, spatial-hash "
+                "collisions, subticks 64, v2 (u32) layout; settled for 48 frames (3072 substeps) before the warm-up")
+
+
+def config3_buffers(particles=1_000_000, layout=LAYOUT_V2):
+    """The config-3 workload of bench.py: about `particles` particles (never more) as a blob pile some twenty
+    times wider than tall (deep beds burst under the collision response of compute.wgsl:164-168; shallow ones
+    settle and stay a pile: tools/pile_probe.py).  Returns (Buffers, bounds_size)."""
+    blobs = max(1, particles // 36)
+    layers = max(1, int(round((blobs / 8.6) ** 0.5)))
+    columns = max(1, blobs // layers)
+    return blob_pile_buffers(columns, layers, gap=20.0, layout=layout)

@@ -341,6 +341,44 @@ def test_grid_follows_a_scene_that_leaves_its_frame(sb, oracle, path):
     assert wide == 1
 
 
+@pytest.mark.parametrize("path", [ATOMIC, TILED])
+def test_grid_reframes_with_many_workgroups(sb, oracle, path):
+    """The same switch of frame, but on 24 000 particles: the hash build then runs as ~24 workgroups of
+    k_grid_maintain, which must all take the tight-or-wide decision from ONE published word (a build that bins
+    with two different geometries misses contacts and can scatter records out of bounds).  A sheet of rain with
+    random sideways speeds falls out of the uploaded frame and its drops collide on the way; bits of the oracle's
+    collision scan (its own uniform grid, pinned to the all-pairs loop by tests/test_oracle_kat.py)."""
+    w, h = 200, 120
+    n = w * h
+    u = sb.scenes.hash_uniform(5, 2 * n).reshape(n, 2)
+    pv = np.zeros((n, 6), "f4")
+    k = np.arange(n)
+    pv[:, 0] = 600.0 + 25.0 * (k % w) + 2.0 * u[:, 0]
+    pv[:, 1] = 8600.0 + 25.0 * (k // w)
+    pv[:, 2] = 40.0 * u[:, 1]
+    pv[:, 3] = -150.0
+    buf = sb.Buffers(2, n, 4)
+    buf.set_scene(pv, np.zeros(0, dtype=sb.layout.BEAM_DTYPE[2]))
+    eng = sb.Engine(bounds_size=12000.0, layout=2, max_particles=n, max_beams=4, collision_mode=GRID, path=path)
+    ref = oracle.OracleEngine(12000.0, 10.0, 64, 2, GRID, threads=8)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    assert eng.info("grid_wide") == 0
+    for frame in range(14):
+        eng.frame()
+        ref.frame()
+        if frame in (4, 8):
+            assert_same(eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy()), "frame %d" % frame)
+    got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+    wide = eng.info("grid_wide")
+    eng.sync()
+    eng.destroy()
+    assert np.isfinite(exp.particles).all()
+    assert_same(got, exp, "re-framing with many workgroups, path %d" % path)
+    assert exp.particles[:n, 1].min() < 4000.0   # far below the uploaded frame (it ended near y = 7850)
+    assert wide == 1
+
+
 def leaving_scene(sb):
     parts, beams, base = [], [], 0
     for ox, vx in ((900.0, 15.0), (1500.0, -15.0)):

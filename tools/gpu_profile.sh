@@ -24,7 +24,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_
 python3 $OLDPWD/bench.py --collisions grid --no-cpu-baseline > $OUT/bench_grid.json 2> $OUT/bench_grid.err || { echo grid bench failed; tail -5 $OUT/bench_grid.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grid -- python3 $OLDPWD/bench.py --collisions grid --steps 200 --warmup 16 --no-cpu-baseline > $OUT/trace_grid.log 2>&1 || { echo grid trace failed; exit 1; }
 # config 3 with its contacts active (4000x250 lattice at spacing 22 resting on the floor)
-python3 $OLDPWD/bench.py --config3 --no-cpu-baseline > $OUT/bench_config3_contacts.json 2>/dev/null || echo "config3 contacts bench failed"
+python3 $OLDPWD/bench.py --lattice-on-floor --no-cpu-baseline --no-extra > $OUT/bench_config3_contacts.json 2>/dev/null || echo "config3 contacts bench failed"
 python3 $OLDPWD/bench.py --soup --no-cpu-baseline > $OUT/bench_soup.json 2>/dev/null || echo "soup bench failed"
 python3 $OLDPWD/tools/config3_contacts_check.py 2>/dev/null | grep -v "amdgpu.ids" > $OUT/config3_contacts_check.txt || echo "config3 check failed"
 # one GPU's share of BASELINE configs 4 (500 x 4000 columns x rows) and 5 (1000 x 8000, mixed springs, dt = 1/128)
