@@ -46,6 +46,8 @@ def parse():
                          "response and 8 collision candidates per particle, but no pair closer than 2r in the window)")
     ap.add_argument("--path", choices=["auto", "atomic", "tiled"], default="auto")
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--block-substeps", type=int, default=0,
+                    help="collisions off: substeps per launch of the temporally blocked kernel (0 = engine default, 1 = off)")
     ap.add_argument("--ghost-depth", type=int, default=24,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
     ap.add_argument("--subticks", type=int, default=64)
@@ -365,7 +367,8 @@ def main():
     B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
-                    path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin)
+                    path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin,
+                    block_substeps=a.block_substeps)
     t0 = time.perf_counter()
     eng.write_buffers(buf)
     upload_ms = (time.perf_counter() - t0) * 1e3

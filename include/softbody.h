@@ -84,7 +84,11 @@ typedef struct sb_options {
                               * drift) since the last build.  0 = default: adaptive, starting at 0.4 r and
                               * doubling up to 1.6 r while hashes last 2 substeps or less; > 0 = that skin,
                               * fixed; negative = rebuild every substep */
-    uint32_t reserved[4];
+    uint32_t block_substeps; /* SB_PATH_TILED with SB_COLLIDE_OFF: substeps one launch advances out of LDS and
+                              * registers (temporal blocking over beam-hop rings; same bits as single substeps).
+                              * 0 = default (5), 1 = one launch per substep, at most 8; lowered
+                              * automatically until every tile's region fits the kernel's registers and LDS */
+    uint32_t reserved[3];
 } sb_options;
 
 /* Fill with the reference defaults: bounds 1000, radius 10, subticks 64, 65536/65536, v1,

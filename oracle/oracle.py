@@ -50,6 +50,29 @@ def lib():
     return _LIB
 
 
+_VARIANTS = {}
+
+
+def variant_lib(name):
+    """One of the OTHER conformant readings of the WGSL text (sb_oracle.c SBO_VARIANT: "v1" = normalize by two
+    divisions, "v2" = strain by division, "v3" = both, "v4" = normalize by inverseSqrt, "fma" = contraction
+    allowed), for tools/tolerance_study.py; never the oracle.  None if this CPU cannot run it (fma)."""
+    if name in _VARIANTS:
+        return _VARIANTS[name]
+    if name == "fma" and " fma " not in open("/proc/cpuinfo").read().replace("\n", " "):
+        _VARIANTS[name] = None
+        return None
+    subprocess.run(["make", "-s", "-C", _HERE, "libsboracle_%s.so" % name], check=True)
+    L = ctypes.CDLL(os.path.join(_HERE, "libsboracle_%s.so" % name))
+    vp = ctypes.c_void_p
+    L.sbo_step.argtypes = [ctypes.POINTER(_Params), vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32]
+    L.sbo_step.restype = ctypes.c_int
+    L.sbo_delete.argtypes = [ctypes.POINTER(_Params), vp, vp, vp, ctypes.c_size_t]
+    L.sbo_delete.restype = None
+    _VARIANTS[name] = L
+    return L
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -60,7 +83,10 @@ class OracleEngine:
     engineWorker.ts:580-597, 646-665, 548-579."""
 
     def __init__(self, bounds_size=1000.0, particle_radius=10.0, subticks=64, layout=1,
-                 collision_mode=COLLIDE_ALLPAIRS, threads=1):
+                 collision_mode=COLLIDE_ALLPAIRS, threads=1, variant=None):
+        self._lib = lib() if variant is None else variant_lib(variant)
+        if self._lib is None:
+            raise RuntimeError("oracle variant %r cannot run on this CPU" % variant)
         self.subticks = int(-(-int(subticks) // 2) * 2)  # engineWorker.ts:90
         self.prm = _Params(np.float32(bounds_size), np.float32(particle_radius),
                            np.float32(np.float32(1.0) / np.float32(self.subticks)),
@@ -90,12 +116,12 @@ class OracleEngine:
 
     def step(self, n):
         a, b = (self.particles_a, self.particles_b) if not self.final_in_b else (self.particles_b, self.particles_a)
-        r = lib().sbo_step(ctypes.byref(self.prm), _p(self.metadata), _p(a), _p(b), _p(self.beams),
+        r = self._lib.sbo_step(ctypes.byref(self.prm), _p(self.metadata), _p(a), _p(b), _p(self.beams),
                            _p(self.mapping), _p(self.forces), _p(self.delete), n)
         self.final_in_b ^= r
 
     def delete_pass(self):
-        lib().sbo_delete(ctypes.byref(self.prm), _p(self.metadata), _p(self.mapping), _p(self.delete),
+        self._lib.sbo_delete(ctypes.byref(self.prm), _p(self.metadata), _p(self.mapping), _p(self.delete),
                          self.delete_words)
 
     def frame(self):

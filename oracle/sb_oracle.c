@@ -50,10 +50,27 @@ static inline float f_abs(float x)
 }
 static inline float v_length(v2 v) { return sqrtf(v.x * v.x + v.y * v.y); }
 static inline float v_dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+/* SBO_VARIANT (default 0 = the canonical arithmetic above) builds the OTHER readings of the WGSL text that a
+ * conformant WebGPU implementation may take, for tools/tolerance_study.py only (never used as the oracle):
+ *   bit 0: normalize(v) = (v.x / length(v), v.y / length(v))   two IEEE divisions, the literal reading
+ *   bit 1: strain = (len - target) / length                    one IEEE division, the literal reading of :112
+ *   bit 2: normalize(v) = v * inverseSqrt(dot(v, v))           the usual back-end lowering, inverseSqrt correctly rounded
+ * (plus -ffp-contract=fast -mfma at build time for the "contraction allowed" variant, see oracle/Makefile). */
+#ifndef SBO_VARIANT
+#define SBO_VARIANT 0
+#endif
 static inline v2 v_normalize(v2 v)
 {
+#if SBO_VARIANT & 1
+    float len = v_length(v);
+    v2 r = { v.x / len, v.y / len };
+#elif SBO_VARIANT & 4
+    float inv = (float)(1.0 / sqrt((double)(v.x * v.x + v.y * v.y)));
+    v2 r = { v.x * inv, v.y * inv };
+#else
     float inv = 1.0f / v_length(v);
     v2 r = { v.x * inv, v.y * inv };
+#endif
     return r;
 }
 
@@ -271,7 +288,11 @@ static void beam_update(const sbo_params *prm, const meta_t *md, const uint8_t *
     float force_mag = (target_length - len) * spring + (last_length - len) * damp;
     v2 n = v_normalize(diff);
     v2 force = { force_mag * n.x, force_mag * n.y };
+#if SBO_VARIANT & 2
+    float strain = (len - target_length) / length;
+#else
     float strain = (len - target_length) * (1.0f / length); /* x / y pinned as x * (1/y), see header */
+#endif
     /* :113-116 */
     if (f_abs(strain) > yield_strain) {
         target_length = len - yield_strain * length * f_sign(strain);

@@ -65,6 +65,7 @@ static void free_scene(sb_engine *e)
     for (void *p : e->mapped) (void)hipIpcCloseMemHandle(p);
     e->mapped.clear();
     e->mailbox = nullptr; // was in allocs
+    e->bk = SbBlockedDev{};
     e->n_peers = e->peer_seq = e->send_floats = e->recv_floats = 0;
     if (e->dev_err) *e->dev_err = 0;
 }
@@ -95,6 +96,133 @@ static inline void map_set(const sb_engine *e, uint8_t *m, size_t id, uint32_t v
     }
 }
 static inline uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+// material dictionary: beams that share (length, spring, damp, yield, limit) share one table row; mode 2 = rows with
+// the rest length, mode 1 = rows without it (arbitrary rest lengths travel per beam), 0 = more rows than `cap`
+struct SbMatDict {
+    uint32_t mode = 0;
+    std::vector<float> table; // [rows][6] = length, spring, damp, yield, limit, 1/length
+    std::vector<uint32_t> of_slot;
+};
+static void build_material_dictionary(SbMatDict &d, const std::vector<SbHostBeam> &hb, uint32_t cap)
+{
+    const uint32_t B = (uint32_t)hb.size();
+    struct Key { uint32_t w[5]; bool operator==(const Key &o) const { return memcmp(w, o.w, sizeof w) == 0; } };
+    struct KeyHash { size_t operator()(const Key &k) const { size_t h = 1469598103934665603ull; for (uint32_t x : k.w) h = (h ^ x) * 1099511628211ull; return h; } };
+    d.of_slot.assign(B, 0);
+    d.mode = 0;
+    d.table.clear();
+    for (int mode = 2; mode >= 1 && cap; mode--) {
+        std::unordered_map<Key, uint32_t, KeyHash> dict;
+        std::vector<float> table;
+        bool ok = true;
+        for (uint32_t s = 0; s < B && ok; s++) {
+            Key k;
+            const float *f = hb[s].f; // length, target, last, spring, damp, yield, limit
+            float row[5] = {mode == 2 ? f[0] : 0.0f, f[3], f[4], f[5], f[6]};
+            memcpy(k.w, row, sizeof row);
+            auto it = dict.find(k);
+            if (it == dict.end()) {
+                if (dict.size() >= cap) { ok = false; break; }
+                it = dict.emplace(k, (uint32_t)dict.size()).first;
+                table.insert(table.end(), row, row + 5);
+                table.push_back(mode == 2 ? 1.0f / row[0] : 0.0f); // 1 / length: one IEEE divide per material
+            }
+            d.of_slot[s] = it->second;
+        }
+        if (ok) {
+            d.mode = (uint32_t)mode;
+            d.table.swap(table);
+            return;
+        }
+    }
+}
+
+template <typename T>
+static sb_status dev_upload(sb_engine *e, T **p, const std::vector<T> &v)
+{
+    SB_TRY(dev_alloc(e, p, v.size()));
+    if (!v.empty()) SB_HIP(e, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SB_OK;
+}
+
+// device side of the temporally blocked plan; on return blockK is 0 if the scene cannot use it (more material rows
+// than the 8 spare bits of an entry word address) and the caller falls back to the single-substep tiling
+static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::vector<SbHostBeam> &hb, uint32_t &blockK)
+{
+    const uint32_t B = (uint32_t)hb.size(), T = bl.ntiles;
+    SbMatDict md;
+    build_material_dictionary(md, hb, 1u << (32u - 2u * SB_BK_LBITS));
+    bool plain_yield = true; // sb_beam_group applies sign(strain) as a copied sign bit, exact for yield_strain >= 0
+    for (size_t r = 0; r < md.table.size(); r += 6) plain_yield = plain_yield && md.table[r + 3] >= 0.0f;
+    if (md.mode == 0 || !plain_yield) {
+        blockK = 0;
+        return SB_OK;
+    }
+    SbBlockedDev &k = e->bk;
+    k.K = blockK;
+    k.cap = bl.max_region;
+    k.dummy_word = (SB_BK_MAXP * SB_BK_T) | ((SB_BK_MAXP * SB_BK_T + 1u) << SB_BK_LBITS); // the two dummy LDS records, material row 0
+    k.cur = 0;
+    k.entries = bl.ent_la.size();
+    k.halo_entries = bl.ent_state.size();
+    k.halo_particles = bl.halo_idx.size();
+    e->ntiles = T;
+    e->nhalo = (uint32_t)bl.halo_idx.size();
+    e->tile_cap_own = bl.max_own;
+    e->tile_cap_all = bl.max_region;
+    e->mat_mode = md.mode;
+    e->lbits = SB_BK_LBITS;
+    e->nmat = (uint32_t)(md.table.size() / 6);
+    e->nbeam = B;
+    e->h_copy_of_slot = bl.g_of_slot;
+    std::vector<uint32_t> words(bl.ent_la.size());
+    std::vector<float> lengths;
+    if (md.mode == 1) lengths.resize(words.size());
+    for (size_t j = 0; j < words.size(); j++) {
+        const uint32_t s = bl.ent_slot[j];
+        words[j] = bl.ent_la[j] | (bl.ent_lb[j] << SB_BK_LBITS) | (md.of_slot[s] << (2u * SB_BK_LBITS));
+        if (md.mode == 1) lengths[j] = hb[s].f[0];
+    }
+    SB_TRY(dev_upload(e, &k.d_tile_p0, bl.tile_p0));
+    SB_TRY(dev_upload(e, &k.d_tile_h0, bl.tile_h0));
+    SB_TRY(dev_upload(e, &k.d_halo_idx, bl.halo_idx));
+    SB_TRY(dev_upload(e, &k.d_ring_cnt, bl.ring_cnt));
+    SB_TRY(dev_upload(e, &k.d_tile_b0, bl.tile_b0));
+    SB_TRY(dev_upload(e, &k.d_tile_e0, bl.tile_e0));
+    SB_TRY(dev_upload(e, &k.d_tile_s0, bl.tile_s0));
+    SB_TRY(dev_upload(e, &k.d_ent_word, words));
+    SB_TRY(dev_upload(e, &k.d_ent_state, bl.ent_state));
+    SB_TRY(dev_upload(e, &k.d_lvl_cnt, bl.lvl_cnt));
+    SB_TRY(dev_upload(e, &k.d_tile_n0, bl.tile_n0));
+    SB_TRY(dev_upload(e, &k.d_tile_nb, bl.tile_nb));
+    SB_TRY(dev_upload(e, &k.d_slot_e0, bl.slot_e0));
+    SB_TRY(dev_upload(e, &k.d_slot_ent, bl.slot_ent));
+    SB_TRY(dev_upload(e, &k.d_ent_length, lengths));
+    SB_TRY(dev_upload(e, &e->d_mat, md.table));
+    SB_TRY(dev_upload(e, &e->beams.slot, bl.beam_slot));
+    // beam state, one entry per beam in owner order; buffer 0 = uploaded, buffer 1 = scratch
+    std::vector<float> tmp(B);
+    float **dst[4] = {&k.d_target[0], &k.d_last[0], &e->beams.strain, &e->beams.stress};
+    const int field[4] = {1, 2, 7, 8};
+    for (int a = 0; a < 4; a++) {
+        for (uint32_t g = 0; g < B; g++) tmp[g] = hb[bl.beam_slot[g]].f[field[a]];
+        SB_TRY(dev_upload(e, dst[a], tmp));
+    }
+    SB_TRY(dev_alloc(e, &k.d_target[1], B));
+    SB_TRY(dev_alloc(e, &k.d_last[1], B));
+    SB_HIP(e, hipMemset(k.d_target[1], 0, std::max<size_t>(B, 1) * 4));
+    SB_HIP(e, hipMemset(k.d_last[1], 0, std::max<size_t>(B, 1) * 4));
+    e->beams.target = k.d_target[0];
+    e->beams.last = k.d_last[0];
+    // buffer A holds whatever accelerations were uploaded; buffer B is all zeros (engineWorker.ts:593)
+    SB_TRY(dev_alloc(e, &e->d_acc_flag[0], T));
+    SB_TRY(dev_alloc(e, &e->d_acc_flag[1], T));
+    SB_HIP(e, hipMemset(e->d_acc_flag[0], 0x01, std::max<size_t>(T, 1) * 4));
+    SB_HIP(e, hipMemset(e->d_acc_flag[1], 0x00, std::max<size_t>(T, 1) * 4));
+    e->lds_bytes = (size_t)e->nmat * 8 * sizeof(float); // the dynamic part: material rows (particles and sums are static)
+    return SB_OK;
+}
 
 extern "C" {
 
@@ -270,11 +398,26 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         memcpy(&py[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE + 4, 4);
     }
     SbTiling tl;
+    SbBlocking bl;
+    uint32_t blockK = 0; // > 0: the temporally blocked plan is in use (sb_blocking.h)
     std::vector<uint32_t> order; // internal -> slot
     if (e->path == SB_PATH_TILED) {
         uint32_t target = e->opt.tile_particles ? e->opt.tile_particles : 1024;
-        sb_build_tiling(tl, px, py, hb, target);
-        order = tl.order;
+        if (e->opt.collision_mode == SB_COLLIDE_OFF && e->opt.block_substeps != 1 && P && B) {
+            // K substeps per launch, K as large as asked for while every tile's region still fits the kernel's
+            // per-thread register arrays and 12-bit local indices
+            const uint32_t region_cap = std::min<uint32_t>(SB_BK_MAXP * SB_BK_T, (1u << SB_BK_LBITS) - 2u);
+            for (blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : 5u, SB_BK_KMAX); blockK; blockK--) {
+                sb_build_blocking(bl, px, py, hb, target, blockK);
+                if (bl.max_region <= region_cap && bl.max_entries <= SB_BK_MAXB * SB_BK_T) break;
+            }
+        }
+        if (blockK) {
+            order = bl.order;
+        } else {
+            sb_build_tiling(tl, px, py, hb, target);
+            order = tl.order;
+        }
     } else {
         order.resize(P);
         std::iota(order.begin(), order.end(), 0u);
@@ -316,7 +459,15 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     std::vector<uint32_t> c_ia, c_ib, c_pair, c_slot;
     std::vector<float> mat_table;
     e->h_copy_of_slot.assign(B, 0);
-    if (e->path == SB_PATH_TILED) {
+    e->bk = SbBlockedDev{};
+    e->beams = SbBeamArrays{};
+    if (blockK) {
+        SB_TRY(upload_blocked(e, bl, hb, blockK));
+        if (!blockK) // no dictionary: the single-substep tiling after all (same bisection, hence the same particle order)
+            sb_build_tiling(tl, px, py, hb, e->opt.tile_particles ? e->opt.tile_particles : 1024);
+    }
+    if (blockK) {
+    } else if (e->path == SB_PATH_TILED) {
         e->ntiles = tl.ntiles;
         e->nhalo = (uint32_t)tl.halo_idx.size();
         c_slot = tl.copy_slot;
@@ -398,9 +549,9 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             e->h_copy_of_slot[s] = s;
         }
     }
-    const uint32_t nc = (uint32_t)c_slot.size();
+    const uint32_t nc = blockK ? e->nbeam : (uint32_t)c_slot.size();
     e->nbeam = nc;
-    {
+    if (!blockK) {
         float *SbBeamArrays::*fields[9] = {&SbBeamArrays::length, &SbBeamArrays::target, &SbBeamArrays::last,
                                            &SbBeamArrays::spring, &SbBeamArrays::damp,   &SbBeamArrays::yield,
                                            &SbBeamArrays::limit,  &SbBeamArrays::strain, &SbBeamArrays::stress};
@@ -563,14 +714,21 @@ sb_status sb_get_physics_constants(sb_engine *e, float c8[8])
     return SB_OK;
 }
 
+// n substeps.  strain/stress are pure outputs (render inputs in the reference, render.wgsl:82): only the last
+// substep before control returns to the caller can ever be observed, so only it stores them.
+static void launch_substeps(sb_engine *e, uint32_t n)
+{
+    if (e->bk.K) sbk_launch_blocked(e, n, true);
+    else
+        for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
+}
+
 sb_status sb_step(sb_engine *e, uint32_t n)
 {
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
-    // strain/stress are pure outputs (render inputs in the reference, render.wgsl:82): only the
-    // last substep before control returns to the caller can ever be observed, so only it stores them
-    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
+    launch_substeps(e, n);
     SB_HIP(e, hipGetLastError());
     return SB_OK;
 }
@@ -580,7 +738,8 @@ sb_status sb_delete_pass(sb_engine *e)
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_delete_pass before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
-    sbk_launch_delete(e);
+    if (e->bk.K) sbk_launch_delete_blocked(e);
+    else sbk_launch_delete(e);
     SB_HIP(e, hipGetLastError());
     return SB_OK;
 }
@@ -612,7 +771,7 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step_timed before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipEventRecord(e->ev0, e->stream));
-    for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
+    launch_substeps(e, n);
     SB_HIP(e, hipGetLastError());
     SB_HIP(e, hipEventRecord(e->ev1, e->stream));
     SB_HIP(e, hipEventSynchronize(e->ev1));
@@ -748,6 +907,13 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
 static uint64_t substep_bytes_model(const sb_engine *e)
 {
     const uint64_t P = e->P, nc = e->nbeam;
+    if (e->bk.K) {
+        // one launch = K substeps: every entry word, the state of every halo entry (index + target + last, gathered),
+        // the owned states in and out, own particles in and out, halo particles (index + position + velocity)
+        const uint64_t per_launch = e->bk.entries * (4 + (e->mat_mode == 1 ? 4 : 0)) + e->bk.halo_entries * 12 + nc * 16 + P * 32 +
+                                    e->bk.halo_particles * 20 + (uint64_t)e->ntiles * (8 * 4 + 8 * e->bk.K) + (uint64_t)e->nmat * 24;
+        return per_launch / e->bk.K;
+    }
     if (e->path == SB_PATH_TILED) {
         uint64_t per_copy = 4 /* endpoint word */ + 4 /* target */ + 4 + 4 /* last: read, written */;
         if (e->mat_mode <= 1) per_copy += 4;  // per-copy rest length
@@ -765,10 +931,11 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     std::string k(key);
     if (k == "path") *value = e->path;
     else if (k == "substep_hbm_bytes") *value = substep_bytes_model(e);
-    else if (k == "substeps_per_launch") *value = 1;
+    else if (k == "substeps_per_launch") *value = e->bk.K ? e->bk.K : 1;
+    else if (k == "region_particles") *value = e->bk.K ? e->bk.cap : e->tile_cap_all;
     else if (k == "tiles") *value = e->ntiles;
-    else if (k == "beam_copies") *value = e->nbeam;
-    else if (k == "halo_particles") *value = e->nhalo;
+    else if (k == "beam_copies") *value = e->bk.K ? e->bk.entries : e->nbeam;
+    else if (k == "halo_particles") *value = e->bk.K ? e->bk.halo_particles : e->nhalo;
     else if (k == "device_bytes") *value = e->device_bytes;
     else if (k == "substeps_done") *value = e->substeps_done;
     else if (k == "lds_bytes") *value = e->lds_bytes;

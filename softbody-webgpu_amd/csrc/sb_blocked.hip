@@ -1,0 +1,370 @@
+// sb_blocked.hip -- k_substep_blocked: K substeps per launch out of LDS and registers (gfx950, wave64).
+//
+// The plan (which particles and beams a tile needs, ring by ring) is sb_blocking.h's; the arithmetic is
+// sb_physics.h's, the same functions the single-substep kernels call.  One 512-thread workgroup per tile:
+//   load    region particles (own: coalesced; halo: gathered) -> positions in LDS, velocities and
+//           accelerations in registers; the tile's entry words and beam states -> registers; materials -> LDS
+//   k x     beam phase: every thread walks its entries up to this substep's prefix (compute.wgsl:103-130),
+//                       integer force sums by ds_add, new target/last stay in registers
+//           particle phase: consume and clear the sums (compute.wgsl:171-201), new position back to LDS
+//   store   own particles -> WRITE buffers, own beams -> WRITE state arrays (strain/stress: last substep of a call)
+// Between launches nothing but the true state lives in HBM, so uploads, read-backs, the delete pass and the ghost
+// refresh of the multi-GPU path see what they always saw.  Collisions are not blocked (their reach is spatial,
+// not along beams): SB_COLLIDE_GRID keeps the single-substep kernels of sb_kernels.hip.
+#include "sb_engine.h"
+
+#ifndef SB_BK_WAVES
+#define SB_BK_WAVES 4 // waves per SIMD the register budget is sized for (2 tiles per CU at 512 threads per tile)
+#endif
+#ifndef SB_BK_G
+#define SB_BK_G 2      // entries evaluated side by side (independent dependency chains in one instruction stream)
+#endif
+
+SB_DEV uint32_t sbb_tile_of_block(uint32_t b, uint32_t n)
+{
+    uint32_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3; // contiguous runs of tiles per XCD (sb_kernels.hip)
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+struct SbBlockedPlan {
+    const uint32_t *tile_p0, *tile_h0, *halo_idx, *ring_cnt, *tile_b0, *tile_e0, *tile_s0, *ent_word, *ent_state, *lvl_cnt,
+        *tile_n0, *tile_nb;
+    const float *ent_length; // MAT == 1: rest length per entry
+    const float *mat_tab;    // [nmat][SB_MAT_ROW]
+    uint32_t ntiles, K, cap, nmat, dummy_word;
+};
+
+struct SbBlockedState {
+    const float *target_r, *last_r;
+    float *target_w, *last_w, *strain, *stress;
+    uint32_t *broken;
+};
+
+#define SB_BK_CAP (SB_BK_MAXP * SB_BK_T + 2u) // LDS records: a full region, then the two dummy endpoints
+#define SB_BK_DUMMY_A (SB_BK_CAP - 2u)
+#define SB_BK_DUMMY_B (SB_BK_CAP - 1u)
+#define SB_BK_ROW 8u // LDS material row: length, 1/length, spring, damp, yield, yield*length, length*limit, limit
+
+template <int MAT, bool AUX>
+__global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(SB_BK_WAVES, SB_BK_WAVES))) void k_substep_blocked(
+    SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
+    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, uint32_t dephase_lo, uint32_t dephase_hi, uint32_t dephase_ticks)
+{
+    // De-phasing: every workgroup of the first round starts at the same instant, so the whole chip loads, then computes,
+    // then stores in lock-step and HBM and the VALUs take turns idling.  The second half of the first round therefore
+    // starts late by about one load phase: it loads while the first half computes, and the rounds after it inherit the shift.
+    if (blockIdx.x >= dephase_lo && blockIdx.x < dephase_hi) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < dephase_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+    // static LDS layout: every address below is a register plus an immediate offset
+    __shared__ float2 s_pos[SB_BK_CAP];
+    __shared__ int s_fx[SB_BK_CAP], s_fy[SB_BK_CAP]; // fixed-point force sums (x and y apart: consecutive particles, consecutive banks)
+    extern __shared__ __attribute__((aligned(16))) float s_mat[]; // [nmat][SB_BK_ROW]
+
+    const uint32_t tile = sbb_tile_of_block(blockIdx.x, bp.ntiles), tid = threadIdx.x, K = bp.K;
+    const uint32_t p0 = bp.tile_p0[tile], n_own = bp.tile_p0[tile + 1] - p0, h0 = bp.tile_h0[tile];
+    const uint32_t *rc = bp.ring_cnt + (size_t)tile * (K + 1), *lc = bp.lvl_cnt + (size_t)tile * K;
+    const uint32_t b0 = bp.tile_b0[tile], n_ownb = bp.tile_b0[tile + 1] - b0, e0 = bp.tile_e0[tile], s0 = bp.tile_s0[tile];
+    const uint32_t np_load = rc[k_run];       // ring <= k_run: everything this launch reads
+    const uint32_t np_move = rc[k_run - 1];   // ring <= k_run - 1: everything it integrates at least once
+    const uint32_t ne_load = lc[k_run - 1];
+    const uint32_t lmask = (1u << SB_BK_LBITS) - 1u;
+
+    // acceleration flags (DESIGN.md 4.1 "zero accelerations"): own tile, and the tiles that own the halo
+    const bool acc_r = __hip_atomic_load(&acc_flag_r[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    const bool acc_w_dirty = __hip_atomic_load(&acc_flag_w[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    bool nb_acc = false;
+    {
+        const uint32_t n0 = bp.tile_n0[tile], nn = bp.tile_n0[tile + 1] - n0;
+        for (uint32_t i = tid; i < nn; i += SB_BK_T)
+            nb_acc |= __hip_atomic_load(&acc_flag_r[bp.tile_nb[n0 + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    }
+
+    // ---- load, in two waves of requests: (1) everything whose address follows from the tile tables -- own particles, own
+    // beam states, entry words, and the INDICES of the halo -- all issued back to back; (2) the halo gathers those indices
+    // name.  (Taking own data through the same index path as the halo made every load wait for the index loads: one more
+    // full memory latency per launch, and the load phase is latency-bound.)
+    uint32_t hidx[SB_BK_MAXP];
+    float2 pp[SB_BK_MAXP], pv[SB_BK_MAXP], pa[SB_BK_MAXP];
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXP; i++) {
+        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+        hidx[i] = (q >= n_own && q < np_load) ? bp.halo_idx[h0 + q - n_own] : 0xFFFFFFFFu;
+    }
+    uint32_t word[SB_BK_MAXB], sidx[SB_BK_MAXB];
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        word[i] = j < ne_load ? bp.ent_word[e0 + j] : bp.dummy_word;
+        sidx[i] = (j >= n_ownb && j < ne_load) ? bp.ent_state[s0 + j - n_ownb] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXP; i++) {
+        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+        pp[i] = pv[i] = pa[i] = make_float2(0.f, 0.f);
+        if (q < n_own) {
+            pp[i] = r.pos[p0 + q];
+            pv[i] = r.vel[p0 + q];
+            if (acc_r) pa[i] = r.acc[p0 + q];
+        }
+    }
+    float tg[SB_BK_MAXB], ls[SB_BK_MAXB], ln[SB_BK_MAXB], iln[SB_BK_MAXB];
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        tg[i] = ls[i] = ln[i] = 1.0f;
+        if (j < n_ownb) {
+            tg[i] = bs.target_r[b0 + j];
+            ls[i] = bs.last_r[b0 + j];
+        }
+        if (MAT == 1 && j < ne_load) ln[i] = bp.ent_length[e0 + j];
+    }
+    // (2) the gathers
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXP; i++) {
+        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+        if (hidx[i] != 0xFFFFFFFFu) {
+            pp[i] = r.pos[hidx[i]];
+            if (q < np_move) pv[i] = r.vel[hidx[i]];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXB; i++) {
+        if (sidx[i] != 0xFFFFFFFFu) {
+            tg[i] = bs.target_r[sidx[i]];
+            ls[i] = bs.last_r[sidx[i]];
+        }
+    }
+    // halo accelerations: only when a tile that owns part of the halo has any (almost never: DESIGN.md 4.1)
+    if (__syncthreads_or(nb_acc ? 1 : 0)) {
+#pragma unroll
+        for (int i = 0; i < SB_BK_MAXP; i++) {
+            const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+            if (hidx[i] != 0xFFFFFFFFu && q < np_move) pa[i] = r.acc[hidx[i]];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXP; i++) {
+        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+        if (q < np_load) {
+            s_pos[q] = pp[i];
+            s_fx[q] = 0;
+            s_fy[q] = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXB; i++) iln[i] = MAT == 1 ? sb_div(1.0f, ln[i]) : 1.0f; // one IEEE divide per entry and launch
+    if (tid == 0) { // the endpoints of dead and padding entries: a unit beam nobody owns
+        s_pos[SB_BK_DUMMY_A] = make_float2(0.f, 0.f);
+        s_pos[SB_BK_DUMMY_B] = make_float2(1.f, 0.f);
+        s_fx[SB_BK_DUMMY_A] = s_fy[SB_BK_DUMMY_A] = s_fx[SB_BK_DUMMY_B] = s_fy[SB_BK_DUMMY_B] = 0;
+    }
+    for (uint32_t i = tid; i < bp.nmat; i += SB_BK_T) { // host row: length, spring, damp, yield, limit, 1/length
+        const float *h = bp.mat_tab + 6u * i;
+        float *d = s_mat + SB_BK_ROW * i;
+        d[0] = h[0];
+        d[1] = h[5];
+        d[2] = h[1];
+        d[3] = h[2];
+        d[4] = h[3];
+        d[5] = h[3] * h[0]; // yield_strain * length, the first product of compute.wgsl:115
+        d[6] = h[0] * h[4]; // length * strain_break_limit, :117
+        d[7] = h[4];
+    }
+    uint32_t brk = 0u; // bit i: entry i of this thread crossed its break limit in some substep
+    bool any_acc = false;
+    __syncthreads();
+
+    // this substep's prefixes (entries / particles whose inputs are still the true state); the next substep's are
+    // requested a whole substep ahead, and all of them are wave-uniform
+    uint32_t nbl = __builtin_amdgcn_readfirstlane(lc[k_run - 1]), npr = __builtin_amdgcn_readfirstlane(rc[k_run - 1]);
+#ifdef SB_BK_ABLATE_COMPUTE // diagnostic build (never shipped): load and store phases only
+    for (uint32_t s = 1; s <= k_run && prm.time_step < 0.0f; s++) {
+#else
+    for (uint32_t s = 1; s <= k_run; s++) {
+#endif
+        uint32_t nbl_next = 0u, npr_next = 0u;
+        if (s < k_run) {
+            nbl_next = lc[k_run - s - 1];
+            npr_next = rc[k_run - s - 1];
+        }
+        // ---- beam phase: groups of SB_BK_G entries in straight-line code.  An entry past the prefix (its inputs
+        // are no longer the true state) may ride along in a group: its force lands on particles that are not
+        // integrated any more and its state is never stored (owned entries are always inside the prefix).
+#pragma unroll
+        for (int i0 = 0; i0 < SB_BK_MAXB; i0 += SB_BK_G) {
+            if (tid + (uint32_t)i0 * SB_BK_T < nbl) {
+                float2 qa[SB_BK_G], qb[SB_BK_G];
+                SbBeamMat mt[SB_BK_G];
+                uint32_t la[SB_BK_G], lb[SB_BK_G];
+                float t_in[SB_BK_G], l_in[SB_BK_G], strain[SB_BK_G], stress[SB_BK_G];
+                int32_t fa[SB_BK_G][2], fb[SB_BK_G][2];
+                bool broken[SB_BK_G];
+#pragma unroll
+                for (int u = 0; u < SB_BK_G; u++) {
+                    const int i = i0 + u;
+                    asm volatile("" : "+v"(word[i])); // keep the unpacking inside the loop: hoisted it is 3 registers per entry
+                    la[u] = word[i] & lmask;
+                    lb[u] = (word[i] >> SB_BK_LBITS) & lmask;
+                    const float *row = s_mat + SB_BK_ROW * (word[i] >> (2u * SB_BK_LBITS));
+                    qa[u] = s_pos[la[u]];
+                    qb[u] = s_pos[lb[u]];
+                    mt[u].spring = row[2];
+                    mt[u].damp = row[3];
+                    mt[u].yield_strain = row[4];
+                    if (MAT == 2) {
+                        mt[u].length = row[0];
+                        mt[u].inv_length = row[1];
+                        mt[u].yl = row[5];
+                        mt[u].ll = row[6];
+                    } else {
+                        mt[u].length = ln[i];
+                        mt[u].inv_length = iln[i];
+                        mt[u].yl = row[4] * ln[i];
+                        mt[u].ll = ln[i] * row[7];
+                    }
+                    t_in[u] = tg[i];
+                    l_in[u] = ls[i];
+                }
+                if (AUX && s == k_run) sb_beam_group<SB_BK_G, true>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
+                else sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
+#pragma unroll
+                for (int u = 0; u < SB_BK_G; u++) {
+                    const int i = i0 + u;
+                    tg[i] = t_in[u];
+                    ls[i] = l_in[u];
+                    if (__builtin_expect(broken[u], 0)) brk |= 1u << i;
+                    atomicAdd(&s_fx[la[u]], fa[u][0]);
+                    atomicAdd(&s_fy[la[u]], fa[u][1]);
+                    atomicAdd(&s_fx[lb[u]], fb[u][0]);
+                    atomicAdd(&s_fy[lb[u]], fb[u][1]);
+                    if (AUX && s == k_run) { // strain/stress: outputs of the last substep of a call (compute.wgsl:122-123)
+                        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+                        if (j < n_ownb && word[i] != bp.dummy_word) {
+                            bs.strain[b0 + j] = strain[u];
+                            bs.stress[b0 + j] = stress[u];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- particle phase: consume and clear the complete sums (compute.wgsl:171-201, :184-185)
+#pragma unroll
+        for (int i = 0; i < SB_BK_MAXP; i++) {
+            const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+            if (q < npr) {
+                SbParticle particle;
+                particle.p = s_pos[q];
+                particle.v = pv[i];
+                particle.a = pa[i];
+                const int fx = s_fx[q], fy = s_fy[q];
+                s_fx[q] = 0;
+                s_fy[q] = 0;
+                sb_particle_finish(prm, c, particle, fx, fy);
+                s_pos[q] = particle.p;
+                pv[i] = particle.v;
+                pa[i] = particle.a;
+            }
+        }
+        __syncthreads();
+        nbl = __builtin_amdgcn_readfirstlane(nbl_next);
+        npr = __builtin_amdgcn_readfirstlane(npr_next);
+    }
+
+    // ---- store: own particles, own beams
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXP; i++) {
+        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+        if (q < n_own) {
+            w.pos[p0 + q] = s_pos[q];
+            w.vel[p0 + q] = pv[i];
+            const bool nz = (__float_as_uint(pa[i].x) | __float_as_uint(pa[i].y)) != 0u; // -0.0 counts
+            any_acc |= nz;
+            if (nz || acc_w_dirty) w.acc[p0 + q] = pa[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        if (j < n_ownb) {
+            const bool alive = word[i] != bp.dummy_word;
+            // a beam removed by a delete pass keeps its last state, which still has to travel to the other buffer
+            bs.target_w[b0 + j] = alive ? tg[i] : bs.target_r[b0 + j];
+            bs.last_w[b0 + j] = alive ? ls[i] : bs.last_r[b0 + j];
+            if (alive && ((brk >> i) & 1u)) atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
+        }
+    }
+    const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
+    if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
+}
+
+// delete pass of the blocked layout: every entry of a flagged beam (the owner's and the halo copies in other
+// tiles) turns into the dummy beam; the mapping slot records the pass, as in k_delete (sb_kernels.hip)
+__global__ __launch_bounds__(256) void k_delete_blocked(uint32_t *ent_word, const uint32_t *__restrict__ beam_slot,
+                                                        const uint32_t *__restrict__ slot_e0,
+                                                        const uint32_t *__restrict__ slot_ent, uint32_t nwords, uint32_t nbeam,
+                                                        uint32_t *broken, uint32_t *dead_gen, uint32_t gen, uint32_t dummy_word)
+{
+    const uint32_t wd = blockIdx.x * 256u + threadIdx.x;
+    if (wd >= nwords) return;
+    uint32_t bits = broken[wd];
+    if (!bits) return;
+    broken[wd] = 0;
+    while (bits) {
+        const uint32_t k = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const uint32_t g = wd * 32 + k;
+        if (g >= nbeam) break;
+        const uint32_t s = beam_slot[g];
+        for (uint32_t e = slot_e0[s]; e < slot_e0[s + 1]; e++) ent_word[slot_ent[e]] = dummy_word;
+        dead_gen[s] = gen;
+    }
+}
+
+static inline uint32_t cdiv_b(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// n substeps as ceil(n / K) launches; the last launch of a call also stores strain/stress when write_aux
+void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
+{
+    SbBlockedPlan bp{e->bk.d_tile_p0, e->bk.d_tile_h0, e->bk.d_halo_idx, e->bk.d_ring_cnt, e->bk.d_tile_b0, e->bk.d_tile_e0,
+                     e->bk.d_tile_s0, e->bk.d_ent_word, e->bk.d_ent_state, e->bk.d_lvl_cnt, e->bk.d_tile_n0, e->bk.d_tile_nb,
+                     e->bk.d_ent_length, e->d_mat, e->ntiles, e->bk.K, e->bk.cap, e->nmat, e->bk.dummy_word};
+    static const float dephase_us = [] { const char *v = getenv("SB_BK_DEPHASE_US"); return v ? (float)atof(v) : 0.0f; }();
+    static const uint32_t slots = [] { const char *v = getenv("SB_BK_SLOTS"); return v ? (uint32_t)atoi(v) : 512u; }();
+    const uint32_t dephase_lo = slots / 2, dephase_hi = slots, dephase_ticks = (uint32_t)(dephase_us * 100.0f); // 100 MHz wall clock
+    while (n) {
+        const uint32_t k = n < e->bk.K ? n : e->bk.K;
+        const bool aux = write_aux && k == n;
+        SbBlockedState bs{e->bk.d_target[e->bk.cur], e->bk.d_last[e->bk.cur], e->bk.d_target[e->bk.cur ^ 1u],
+                          e->bk.d_last[e->bk.cur ^ 1u], e->beams.strain, e->beams.stress, e->d_broken};
+        SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
+#define SB_LAUNCH_B(M, A)                                                                                             \
+    k_substep_blocked<M, A><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,      \
+                                                                            e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1], dephase_lo, dephase_hi, dephase_ticks)
+        if (e->ntiles) {
+            if (e->mat_mode == 2) {
+                if (aux) SB_LAUNCH_B(2, true); else SB_LAUNCH_B(2, false);
+            } else {
+                if (aux) SB_LAUNCH_B(1, true); else SB_LAUNCH_B(1, false);
+            }
+        }
+#undef SB_LAUNCH_B
+        e->cur ^= 1;
+        e->bk.cur ^= 1u;
+        e->beams.target = e->bk.d_target[e->bk.cur]; // what read-back, halo pack/unpack and the next launch see
+        e->beams.last = e->bk.d_last[e->bk.cur];
+        e->substeps_done += k;
+        n -= k;
+    }
+}
+
+void sbk_launch_delete_blocked(sb_engine *e)
+{
+    if (!e->nbeam) return;
+    const uint32_t nwords = cdiv_b(e->nbeam, 32);
+    k_delete_blocked<<<cdiv_b(nwords, 256), 256, 0, e->stream>>>(e->bk.d_ent_word, e->beams.slot, e->bk.d_slot_e0, e->bk.d_slot_ent,
+                                                                 nwords, e->nbeam, e->d_broken, e->d_dead_gen, ++e->delete_gen,
+                                                                 e->bk.dummy_word);
+}

@@ -1,0 +1,269 @@
+// sb_blocking.h -- host-side plan for the TEMPORALLY BLOCKED substep kernel (k_substep_blocked).
+//
+// One launch advances every tile by K substeps out of LDS and registers.  That is possible because a
+// substep moves information exactly one beam hop (compute.wgsl:103-130: a beam reads its two endpoints;
+// :183-187: a particle reads the forces of its own beams), so the state of a tile's own particles after K
+// substeps depends only on the particles within K hops of the tile and on the beams between them:
+//   ring(p)   = beam-graph distance of particle p from the tile's own particles (0 = own), for ring <= K
+//   region    = own particles, then the halo sorted by ring
+//   entries   = every beam with an endpoint of ring <= K-1, sorted by the smaller ring of its endpoints
+// In substep s of a launch of k substeps (s = 1..k) the tile evaluates the entries whose smaller ring is
+// <= k-s and integrates the particles of ring <= k-s: exactly the part of the region whose inputs are
+// still the true state.  Everything is redundant, deterministic arithmetic on the same inputs the owner
+// uses, so the result is bit-identical to k single substeps.  Per launch a tile reads its region once
+// and writes its own particles and its own beams once: HBM traffic and launch boundaries per substep drop
+// by about K x (2/3 after the redundant ring work and the halo gathers are paid).
+//
+// Beam state is NOT duplicated here (the single-substep tiling keeps a private copy per tile): each beam
+// has one owner (the tile of its endpoint A) and one slot g in the state arrays, which are double
+// buffered like the particles (other tiles read state t while the owner writes state t+k).
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <thread>
+#include <vector>
+
+#include "sb_tiling.h"
+
+struct SbBlocking {
+    uint32_t ntiles = 0, K = 0;
+    std::vector<uint32_t> order;     // internal particle -> slot (tiles are contiguous ranges)
+    std::vector<uint32_t> tile_p0;   // [T+1] own particles
+    std::vector<uint32_t> tile_h0;   // [T+1] halo ranges
+    std::vector<uint32_t> halo_idx;  // internal particle index of each halo entry (sorted by ring, then index)
+    std::vector<uint32_t> ring_cnt;  // [T][K+1] region particles with ring <= r (ring_cnt[t][0] = own)
+    std::vector<uint32_t> tile_b0;   // [T+1] owned beams = ranges of the state arrays
+    std::vector<uint32_t> beam_slot; // [NB] mapping slot of state index g
+    std::vector<uint32_t> g_of_slot; // [B]
+    std::vector<uint32_t> tile_e0;   // [T+1] entry ranges
+    std::vector<uint32_t> ent_la, ent_lb, ent_slot; // region-local endpoint indices, beam slot
+    std::vector<uint32_t> lvl_cnt;   // [T][K] entries whose smaller ring is <= m (m = 0..K-1)
+    std::vector<uint32_t> tile_s0;   // [T+1] ranges of ent_state (entries past the tile's own beams)
+    std::vector<uint32_t> ent_state; // state index g of each non-owned entry
+    std::vector<uint32_t> slot_e0;   // [B+1] CSR beam slot -> absolute entry indices (delete pass)
+    std::vector<uint32_t> slot_ent;
+    std::vector<uint32_t> tile_n0;   // [T+1] CSR tile -> tiles that own some of its halo particles
+    std::vector<uint32_t> tile_nb;
+    uint32_t max_region = 0, max_entries = 0, max_own = 0;
+};
+
+namespace sbt {
+
+template <typename F>
+inline void parallel_tiles(uint32_t n, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    const uint32_t nt = std::max(1u, std::min<uint32_t>(hw ? hw : 4u, std::min(16u, (n + 31) / 32)));
+    if (nt <= 1) {
+        f(0u, 0u, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (uint32_t w = 0; w < nt; w++)
+        th.emplace_back([=, &f] { f(w, (uint32_t)((uint64_t)n * w / nt), (uint32_t)((uint64_t)n * (w + 1) / nt)); });
+    for (auto &t : th) t.join();
+}
+
+} // namespace sbt
+
+// px,py: position per particle slot; beams: per beam slot, endpoints as particle slots.
+inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const std::vector<float> &py,
+                              const std::vector<SbHostBeam> &beams, uint32_t target, uint32_t K)
+{
+    const uint32_t P = (uint32_t)px.size(), B = (uint32_t)beams.size();
+    target = std::max(64u, std::min(target, 16384u));
+    t.K = K;
+    t.order.resize(P);
+    for (uint32_t i = 0; i < P; i++) t.order[i] = i;
+    t.tile_p0.assign(1, 0);
+    if (P) {
+        sbt::Splitter sp{px, py, t.order, t.tile_p0, target};
+        sp.split(0, P, (P + target - 1) / target);
+    }
+    const uint32_t T = t.ntiles = (uint32_t)t.tile_p0.size() - 1;
+    std::vector<uint32_t> internal_of_slot(P), tile_of(P);
+    for (uint32_t i = 0; i < P; i++) internal_of_slot[t.order[i]] = i;
+    for (uint32_t k = 0; k < T; k++)
+        for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = k;
+
+    // beam endpoints as internal indices; adjacency (particle -> incident beam slots)
+    std::vector<uint32_t> ba(B), bb(B), adj0(P + 1, 0);
+    for (uint32_t s = 0; s < B; s++) {
+        ba[s] = internal_of_slot[beams[s].a];
+        bb[s] = internal_of_slot[beams[s].b];
+        adj0[ba[s] + 1]++;
+        if (bb[s] != ba[s]) adj0[bb[s] + 1]++;
+    }
+    for (uint32_t i = 0; i < P; i++) adj0[i + 1] += adj0[i];
+    std::vector<uint32_t> adj(adj0[P]);
+    {
+        std::vector<uint32_t> cur(adj0.begin(), adj0.end() - 1);
+        for (uint32_t s = 0; s < B; s++) {
+            adj[cur[ba[s]]++] = s;
+            if (bb[s] != ba[s]) adj[cur[bb[s]]++] = s;
+        }
+    }
+    // Order of the beams inside a tile, for the owned state arrays and for every entry list: by the beam's RANK among
+    // the beams that leave its endpoint A (0 = A's first beam in slot order, 1 = its second ...), then by A.  Consecutive
+    // lanes of the kernel then work on consecutive particles -- in a lattice "all the +y beams, then all the +x beams,
+    // then the diagonals" -- so the endpoint gathers and the integer force adds of a wave fall into distinct LDS banks
+    // instead of three or four lanes hitting the same particle (r02: 48 % of the LDS cycles were bank conflicts with
+    // the entries in slot order).
+    std::vector<uint32_t> rank(B);
+    {
+        std::vector<uint32_t> out_cnt(P, 0);
+        for (uint32_t s = 0; s < B; s++) rank[s] = out_cnt[ba[s]]++;
+    }
+    // owned beams: tile of endpoint A
+    t.tile_b0.assign(T + 1, 0);
+    for (uint32_t s = 0; s < B; s++) t.tile_b0[tile_of[ba[s]] + 1]++;
+    for (uint32_t k = 0; k < T; k++) t.tile_b0[k + 1] += t.tile_b0[k];
+    t.beam_slot.assign(B, 0);
+    t.g_of_slot.assign(B, 0);
+    {
+        std::vector<uint32_t> cur(t.tile_b0.begin(), t.tile_b0.end() - 1);
+        for (uint32_t s = 0; s < B; s++) t.beam_slot[cur[tile_of[ba[s]]]++] = s;
+        for (uint32_t k = 0; k < T; k++)
+            std::sort(t.beam_slot.begin() + t.tile_b0[k], t.beam_slot.begin() + t.tile_b0[k + 1], [&](uint32_t x, uint32_t y) {
+                if (rank[x] != rank[y]) return rank[x] < rank[y];
+                if (ba[x] != ba[y]) return ba[x] < ba[y];
+                return x < y;
+            });
+        for (uint32_t g = 0; g < B; g++) t.g_of_slot[t.beam_slot[g]] = g;
+    }
+
+    // per tile: rings, region, entries (tiles are independent: a few host threads)
+    struct TileOut {
+        std::vector<uint32_t> halo, ring_cnt, la, lb, slot, lvl_cnt, state, nb;
+    };
+    std::vector<TileOut> out(T);
+    sbt::parallel_tiles(T, [&](uint32_t, uint32_t k0, uint32_t k1) {
+        std::vector<uint32_t> stamp(P, 0xFFFFFFFFu), local(P, 0);
+        std::vector<uint8_t> ring(P, 0);
+        std::vector<uint32_t> frontier, next;
+        struct Ent { uint32_t m, owned, slot; };
+        std::vector<Ent> ents;
+        for (uint32_t k = k0; k < k1; k++) {
+            TileOut &o = out[k];
+            const uint32_t p0 = t.tile_p0[k], p1 = t.tile_p0[k + 1], n_own = p1 - p0;
+            frontier.clear();
+            for (uint32_t i = p0; i < p1; i++) {
+                stamp[i] = k;
+                ring[i] = 0;
+                local[i] = i - p0;
+                frontier.push_back(i);
+            }
+            o.ring_cnt.assign(K + 1, n_own);
+            o.halo.clear();
+            for (uint32_t r = 1; r <= K; r++) {
+                next.clear();
+                for (uint32_t p : frontier)
+                    for (uint32_t e = adj0[p]; e < adj0[p + 1]; e++) {
+                        const uint32_t s = adj[e], q = ba[s] == p ? bb[s] : ba[s];
+                        if (stamp[q] != k) {
+                            stamp[q] = k;
+                            ring[q] = (uint8_t)r;
+                            next.push_back(q);
+                        }
+                    }
+                std::sort(next.begin(), next.end());
+                for (uint32_t q : next) {
+                    local[q] = n_own + (uint32_t)o.halo.size();
+                    o.halo.push_back(q);
+                }
+                o.ring_cnt[r] = n_own + (uint32_t)o.halo.size();
+                frontier.swap(next);
+            }
+            // entries: every beam with an endpoint of ring <= K-1, once
+            ents.clear();
+            auto visit = [&](uint32_t p) {
+                if (ring[p] > K - 1) return;
+                for (uint32_t e = adj0[p]; e < adj0[p + 1]; e++) {
+                    const uint32_t s = adj[e];
+                    const uint32_t a = ba[s], b = bb[s];
+                    // the beam is emitted by endpoint A, unless A lies outside the rings that emit (then by B)
+                    const bool a_emits = stamp[a] == k && ring[a] <= K - 1;
+                    if (p == a ? true : !a_emits) {
+                        if (p != a && p != b) continue;
+                        const uint32_t m = std::min<uint32_t>(ring[a], ring[b]);
+                        ents.push_back(Ent{m, tile_of[a] == k ? 0u : 1u, s});
+                    }
+                }
+            };
+            for (uint32_t i = p0; i < p1; i++) visit(i);
+            for (uint32_t q : o.halo) visit(q);
+            std::sort(ents.begin(), ents.end(), [&](const Ent &x, const Ent &y) {
+                if (x.m != y.m) return x.m < y.m;
+                if (x.owned != y.owned) return x.owned < y.owned;
+                if (rank[x.slot] != rank[y.slot]) return rank[x.slot] < rank[y.slot];
+                if (ba[x.slot] != ba[y.slot]) return ba[x.slot] < ba[y.slot];
+                return x.slot < y.slot;
+            });
+            const size_t n = ents.size();
+            o.la.resize(n);
+            o.lb.resize(n);
+            o.slot.resize(n);
+            o.state.clear();
+            o.lvl_cnt.assign(K, 0);
+            for (size_t j = 0; j < n; j++) {
+                const uint32_t s = ents[j].slot;
+                o.la[j] = local[ba[s]];
+                o.lb[j] = local[bb[s]];
+                o.slot[j] = s;
+                if (ents[j].owned) o.state.push_back(t.g_of_slot[s]);
+                for (uint32_t m = ents[j].m; m < K; m++) o.lvl_cnt[m]++;
+            }
+            // tiles that own my halo particles (their acceleration flags decide whether halo a's are read)
+            o.nb.clear();
+            for (uint32_t q : o.halo) o.nb.push_back(tile_of[q]);
+            std::sort(o.nb.begin(), o.nb.end());
+            o.nb.erase(std::unique(o.nb.begin(), o.nb.end()), o.nb.end());
+        }
+    });
+
+    t.tile_h0.assign(T + 1, 0);
+    t.tile_e0.assign(T + 1, 0);
+    t.tile_s0.assign(T + 1, 0);
+    t.tile_n0.assign(T + 1, 0);
+    t.max_region = t.max_entries = t.max_own = 0;
+    for (uint32_t k = 0; k < T; k++) {
+        t.tile_h0[k + 1] = t.tile_h0[k] + (uint32_t)out[k].halo.size();
+        t.tile_e0[k + 1] = t.tile_e0[k] + (uint32_t)out[k].la.size();
+        t.tile_s0[k + 1] = t.tile_s0[k] + (uint32_t)out[k].state.size();
+        t.tile_n0[k + 1] = t.tile_n0[k] + (uint32_t)out[k].nb.size();
+        const uint32_t own = t.tile_p0[k + 1] - t.tile_p0[k];
+        t.max_own = std::max(t.max_own, own);
+        t.max_region = std::max(t.max_region, own + (uint32_t)out[k].halo.size());
+        t.max_entries = std::max(t.max_entries, (uint32_t)out[k].la.size());
+    }
+    t.halo_idx.resize(t.tile_h0[T]);
+    t.ring_cnt.resize((size_t)T * (K + 1));
+    t.lvl_cnt.resize((size_t)T * K);
+    const uint32_t E = t.tile_e0[T];
+    t.ent_la.resize(E);
+    t.ent_lb.resize(E);
+    t.ent_slot.resize(E);
+    t.ent_state.resize(t.tile_s0[T]);
+    t.tile_nb.resize(t.tile_n0[T]);
+    t.slot_e0.assign(B + 1, 0);
+    for (uint32_t k = 0; k < T; k++) {
+        const TileOut &o = out[k];
+        std::copy(o.halo.begin(), o.halo.end(), t.halo_idx.begin() + t.tile_h0[k]);
+        std::copy(o.ring_cnt.begin(), o.ring_cnt.end(), t.ring_cnt.begin() + (size_t)k * (K + 1));
+        std::copy(o.lvl_cnt.begin(), o.lvl_cnt.end(), t.lvl_cnt.begin() + (size_t)k * K);
+        std::copy(o.la.begin(), o.la.end(), t.ent_la.begin() + t.tile_e0[k]);
+        std::copy(o.lb.begin(), o.lb.end(), t.ent_lb.begin() + t.tile_e0[k]);
+        std::copy(o.slot.begin(), o.slot.end(), t.ent_slot.begin() + t.tile_e0[k]);
+        std::copy(o.state.begin(), o.state.end(), t.ent_state.begin() + t.tile_s0[k]);
+        std::copy(o.nb.begin(), o.nb.end(), t.tile_nb.begin() + t.tile_n0[k]);
+        for (uint32_t s : o.slot) t.slot_e0[s + 1]++;
+    }
+    for (uint32_t s = 0; s < B; s++) t.slot_e0[s + 1] += t.slot_e0[s];
+    t.slot_ent.resize(E);
+    {
+        std::vector<uint32_t> cur(t.slot_e0.begin(), t.slot_e0.end() - 1);
+        for (uint32_t e = 0; e < E; e++) t.slot_ent[cur[t.ent_slot[e]]++] = e;
+    }
+}

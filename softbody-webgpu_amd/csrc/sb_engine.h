@@ -9,6 +9,7 @@
 #include "../../include/softbody.h"
 #include "sb_physics.h"
 #include "sb_tiling.h"
+#include "sb_blocking.h"
 
 // Device SoA of the beam working set.  One entry per beam COPY: the atomic path keeps one
 // copy per active slot (slot order); the tiled path keeps per-tile slices in which a beam
@@ -22,6 +23,32 @@ struct SbBeamArrays {
 
 struct SbParticleArrays {
     float2 *pos, *vel, *acc;
+};
+
+#define SB_BK_LBITS 12u  // bits per region-local endpoint index of the blocked kernel (regions of up to 4094 particles)
+#ifndef SB_BK_T
+#define SB_BK_T 512u     // threads per tile workgroup of k_substep_blocked
+#endif
+#ifndef SB_BK_MAXB
+#define SB_BK_MAXB (6144 / SB_BK_T) // entries per thread    -> a tile evaluates at most 6144 beams per substep
+#endif
+#ifndef SB_BK_MAXP
+#define SB_BK_MAXP (2560 / SB_BK_T) // particles per thread  -> a region holds at most 2560 particles
+#endif
+#define SB_BK_KMAX 8u
+
+// device side of the temporally blocked plan (sb_blocking.h, sb_blocked.hip)
+struct SbBlockedDev {
+    uint32_t K = 0;           // substeps per launch; 0 = the engine is not running blocked
+    uint32_t cap = 0;         // region capacity = local index of the first dummy endpoint
+    uint32_t dummy_word = 0;  // entry word of dead and padding entries
+    uint32_t cur = 0;         // which beam-state buffer holds the current state
+    uint32_t *d_tile_p0 = nullptr, *d_tile_h0 = nullptr, *d_halo_idx = nullptr, *d_ring_cnt = nullptr, *d_tile_b0 = nullptr,
+             *d_tile_e0 = nullptr, *d_tile_s0 = nullptr, *d_ent_word = nullptr, *d_ent_state = nullptr, *d_lvl_cnt = nullptr,
+             *d_tile_n0 = nullptr, *d_tile_nb = nullptr, *d_slot_e0 = nullptr, *d_slot_ent = nullptr;
+    float *d_ent_length = nullptr;
+    float *d_target[2] = {nullptr, nullptr}, *d_last[2] = {nullptr, nullptr};
+    uint64_t entries = 0, halo_entries = 0, halo_particles = 0; // totals, for the traffic model
 };
 
 struct sb_engine {
@@ -85,6 +112,7 @@ struct sb_engine {
     uint32_t *d_halo_idx = nullptr;   // internal particle index of each halo entry
     size_t lds_bytes = 0;
     uint32_t *d_acc_flag[2] = {nullptr, nullptr}; // per particle buffer, per tile: 0 = every acc is zero
+    SbBlockedDev bk;
     // beam word packing and material dictionary (tiled path)
     uint32_t lbits = 16;      // bits per tile-local endpoint index
     uint32_t mat_mode = 0;    // 0: per-copy parameter arrays; 1: table of (spring,damp,yield,limit) + per-copy length;
@@ -120,3 +148,6 @@ void sbk_launch_delete(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float *src);
 void sbk_launch_peer_exchange(sb_engine *e);
+// sb_blocked.hip
+void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux);
+void sbk_launch_delete_blocked(sb_engine *e);

@@ -231,6 +231,71 @@ SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float inv_l
     return r;
 }
 
+// G beams side by side, for the temporally blocked kernel (sb_blocked.hip): the same arithmetic as sb_beam_eval in
+// the same order, written stage by stage over the group so that the G dependency chains interleave in one
+// instruction stream and ONE wave-uniform gate decides between the short exact sqrt/reciprocal and the IEEE
+// sequences for the whole group.  Per material the host precomputes yl = yield_strain * length (the first product of
+// :115, evaluated left to right) and ll = length * strain_break_limit (:117): same operands, same single rounding.
+// sign(strain) enters :115 only as a factor of +-1 (exact) when |strain| > yield_strain >= 0, so it is applied as a
+// copied sign bit; the host routes scenes with a negative or NaN yield_strain to the single-substep kernel, where
+// sign() is spelled out.
+struct SbBeamMat {
+    float length, inv_length, spring, damp, yield_strain, yl, ll;
+};
+template <int G, bool AUX>
+SB_DEV void sb_beam_group(const float2 (&pa)[G], const float2 (&pb)[G], const SbBeamMat (&m)[G], float (&target)[G],
+                          float (&last)[G], int32_t (&fa)[G][2], int32_t (&fb)[G][2], bool (&broken)[G], float (&strain_out)[G],
+                          float (&stress_out)[G])
+{
+    const float particle_force_scale = 65536.0f; // :70
+    const float beam_stress_scale = 1.0f / 20.0f; // :71
+    float dx[G], dy[G], len2[G], len[G], inv_len[G];
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+        dx[u] = pb[u].x - pa[u].x; // :103
+        dy[u] = pb[u].y - pa[u].y;
+        len2[u] = dx[u] * dx[u] + dy[u] * dy[u];
+        ok = ok && sb_in_sqrt_gate(len2[u]);
+    }
+    if (sb_wave_all(ok)) {
+#pragma unroll
+        for (int u = 0; u < G; u++) len[u] = sb_sqrt_gated(len2[u]); // :108 (the guard of :104 cannot fire)
+#pragma unroll
+        for (int u = 0; u < G; u++) inv_len[u] = sb_rcp_gated(len[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const float len0 = sb_sqrt(len2[u]);
+            const bool degenerate = len0 == 0.0f; // :104-107
+            dx[u] = degenerate ? 0.0f : dx[u];
+            dy[u] = degenerate ? -1.0e-10f : dy[u];
+            len[u] = degenerate ? sb_length(0.0f, -1.0e-10f) : len0;
+            inv_len[u] = sb_div(1.0f, len[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+        const float force_mag = (target[u] - len[u]) * m[u].spring + (last[u] - len[u]) * m[u].damp; // :110
+        const float nx = dx[u] * inv_len[u], ny = dy[u] * inv_len[u];
+        const float sx = force_mag * nx * particle_force_scale, sy = force_mag * ny * particle_force_scale; // :111, :127-130
+        const float strain = (len[u] - target[u]) * m[u].inv_length; // :112
+        const float signed_yl = m[u].yl * __uint_as_float((__float_as_uint(strain) & 0x80000000u) | 0x3f800000u); // * (+-1)
+        const float yielded_target = len[u] - signed_yl; // :115
+        if (AUX) {
+            stress_out[u] = force_mag * beam_stress_scale;                  // :122
+            strain_out[u] = sb_div(sb_abs(strain), m[u].yield_strain);      // :123
+        }
+        target[u] = (sb_abs(strain) > m[u].yield_strain) ? yielded_target : target[u]; // :113-116
+        broken[u] = sb_abs(len[u] - m[u].length) > m[u].ll;                             // :117
+        last[u] = len[u];                                                              // :124
+        fb[u][0] = sb_f32_to_i32(sx);
+        fb[u][1] = sb_f32_to_i32(sy);
+        fa[u][0] = sb_f32_to_i32_neg(sx);
+        fa[u][1] = sb_f32_to_i32_neg(sy);
+    }
+}
+
 // ---------------------------------------------------------------- particle (compute.wgsl:139-201)
 
 struct SbParticle {

@@ -36,7 +36,7 @@ class SbOptions(ctypes.Structure):
                 ("layout", ctypes.c_uint32), ("collision_mode", ctypes.c_uint32),
                 ("path", ctypes.c_uint32), ("tile_particles", ctypes.c_uint32),
                 ("device_ordinal", ctypes.c_int32), ("grid_skin", ctypes.c_float),
-                ("reserved", ctypes.c_uint32 * 4)]
+                ("block_substeps", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3)]
 
 
 _lib = None
@@ -118,7 +118,7 @@ class Engine:
 
     def __init__(self, bounds_size=1000.0, particle_radius=10.0, subticks=64, layout=LAYOUT_V1,
                  max_particles=65536, max_beams=65536, collision_mode=COLLIDE_GRID,
-                 path=PATH_AUTO, tile_particles=0, device=0, grid_skin=0.0):
+                 path=PATH_AUTO, tile_particles=0, device=0, grid_skin=0.0, block_substeps=0):
         L = load_library()
         o = SbOptions()
         L.sb_default_options(ctypes.byref(o))
@@ -126,6 +126,7 @@ class Engine:
         o.max_particles, o.max_beams, o.layout = max_particles, max_beams, layout
         o.collision_mode, o.path, o.tile_particles, o.device_ordinal = collision_mode, path, tile_particles, device
         o.grid_skin = grid_skin
+        o.block_substeps = block_substeps
         self._h = ctypes.c_void_p()
         st = L.sb_create(ctypes.byref(o), ctypes.byref(self._h))
         if st != 0:
@@ -207,6 +208,8 @@ class Engine:
         lists it."""
         if self.info("path") != PATH_TILED:
             return "k_beams_atomic+k_particles"
+        if self.info("substeps_per_launch") > 1:
+            return "k_substep_blocked"
         return "k_substep_tiled_grid" if self.collision_mode == COLLIDE_GRID else "k_substep_tiled"
 
     def sync_quiet(self):
