@@ -372,6 +372,10 @@ def main():
     t0 = time.perf_counter()
     eng.write_buffers(buf)
     upload_ms = (time.perf_counter() - t0) * 1e3
+    if a.config3:
+        for _ in range(sb.scenes.CONFIG3_SETTLE_FRAMES):   # the pile comes to rest on itself (untimed)
+            eng.frame()
+        eng.sync()
     exchange_mode = None
     if plan is None:
         stepper = eng.step
@@ -407,6 +411,8 @@ def main():
         kernel_ms = None
     barrier()
     wall = time.perf_counter() - t0
+    if plan is not None:
+        ex.verify()       # refuses a halo run in which beams broke (break flags do not cross ranks)
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -62,6 +62,8 @@ static void free_scene(sb_engine *e)
     e->device_bytes = 0;
     e->loaded = false;
     e->n_ghost_p = e->n_send_p = e->n_ghost_b = e->n_send_b = e->n_ghost_b_copies = 0;
+    e->d_ghost_p = e->d_send_p = e->d_send_b = e->d_send_p_off = e->d_send_b_off = e->d_ghost_p_off = e->d_ghost_b_off = nullptr;
+    e->d_ghost_b = nullptr;
     for (void *p : e->mapped) (void)hipIpcCloseMemHandle(p);
     e->mapped.clear();
     e->mailbox = nullptr; // was in allocs
@@ -969,6 +971,18 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             *value = (uint64_t)(ctl.skin * 1000.0f + 0.5f);
         }
     }
+    else if (k == "beams_flagged") { // beams flagged by mark_beam_deleted (compute.wgsl:117-121) since the last delete pass
+        *value = 0;
+        const size_t words = ((size_t)e->nbeam + 31) / 32;
+        if (words && e->d_broken) {
+            std::vector<uint32_t> h(words);
+            SB_HIP(e, hipStreamSynchronize(e->stream));
+            SB_HIP(e, hipMemcpy(h.data(), e->d_broken, words * 4, hipMemcpyDeviceToHost));
+            uint64_t n = 0;
+            for (uint32_t w : h) n += (uint64_t)__builtin_popcount(w);
+            *value = n;
+        }
+    }
     else if (k == "material_mode") *value = e->mat_mode;
     else if (k == "materials") *value = e->nmat;
     else if (k == "local_index_bits") *value = e->lbits;
@@ -1016,6 +1030,19 @@ static sb_status sb_halo_configure_impl(sb_engine *e, const uint32_t *ghost_part
         uint32_t s = copy_slot[c];
         if (s != 0xFFFFFFFFu && pos_of_slot[s] != 0xFFFFFFFFu) ghost_copies.push_back(make_uint2(c, pos_of_slot[s]));
     }
+    if (e->mailbox) SB_FAIL(e, SB_ERR_STATE, "sb_halo_configure after sb_peer_mailbox (its size follows the lists): upload again to reconfigure");
+    // a second configuration replaces the first: release its lists now, not at the next upload
+    for (void *old : {(void *)e->d_ghost_p, (void *)e->d_send_p, (void *)e->d_send_b, (void *)e->d_ghost_b, (void *)e->d_send_p_off,
+                      (void *)e->d_send_b_off, (void *)e->d_ghost_p_off, (void *)e->d_ghost_b_off}) {
+        if (!old) continue;
+        auto it = std::find(e->allocs.begin(), e->allocs.end(), old);
+        if (it != e->allocs.end()) {
+            (void)hipFree(old);
+            e->allocs.erase(it);
+        }
+    }
+    e->d_ghost_p = e->d_send_p = e->d_send_b = e->d_send_p_off = e->d_send_b_off = e->d_ghost_p_off = e->d_ghost_b_off = nullptr;
+    e->d_ghost_b = nullptr;
     SB_TRY(dev_alloc(e, &e->d_ghost_p, n_gp));
     SB_TRY(dev_alloc(e, &e->d_send_p, n_sp));
     SB_TRY(dev_alloc(e, &e->d_send_b, n_sb));
@@ -1122,6 +1149,11 @@ sb_status sb_peer_connect(sb_engine *e, uint32_t n_peers, void *const *mailboxes
     if (!e) return SB_ERR_INVALID;
     if (!e->mailbox) SB_FAIL(e, SB_ERR_STATE, "sb_peer_connect before sb_peer_mailbox");
     if (n_peers > SB_MAX_PEERS) SB_FAIL(e, SB_ERR_INVALID, "at most %d neighbours", SB_MAX_PEERS);
+    // The sequence flags in both sides' mailboxes only ever count up.  Re-connecting after exchanges have run would have
+    // to restart them on every side at once; a restart on one side alone makes stale mailbox data look fresh.  A new
+    // upload (sb_write_buffers) releases the mailbox and is the way to start over.
+    if (e->peer_seq != 0)
+        SB_FAIL(e, SB_ERR_STATE, "sb_peer_connect on a mailbox that has already exchanged %u times: upload again to start over", e->peer_seq);
     if (n_peers && (!mailboxes || !peer_recv_floats || !send_begin || !send_len || !dst_begin || !their_slot))
         return SB_ERR_INVALID;
     for (uint32_t j = 0; j < n_peers; j++) {
@@ -1146,7 +1178,6 @@ sb_status sb_peer_connect(sb_engine *e, uint32_t n_peers, void *const *mailboxes
         e->peer_slot[j] = their_slot[j];
     }
     e->peer_timeout_ms = timeout_ms ? timeout_ms : 10000;
-    e->peer_seq = 0;
     return SB_OK;
 }
 

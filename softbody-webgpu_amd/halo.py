@@ -157,11 +157,28 @@ class Exchanger:
     def __init__(self, engine, plan, transport):
         self.engine, self.plan, self.transport = engine, plan, transport
         self.since = 0
+        self.beams_at_start = engine.counts()[1]
         gp, sp, gb, sb_ = plan.lists()
         engine.halo_configure(gp, sp, gb, sb_)
         self.segs, n_send, n_recv, offsets = plan.segments()
         engine.halo_set_layout(*offsets)
         self.send, self.recv = transport.allocate(n_send, n_recv)
+
+    def verify(self):
+        """Limits of the redundant ghost zones, enforced (call after stepping; it drains the engine's stream): a beam
+        that breaks is reconciled between ranks only through its two endpoints' state, not through its break flag -- a
+        ghost copy whose break is not reproduced bit for bit on the owner (its inputs were already invalid) would
+        diverge silently, and no delete pass runs across ranks.  So a halo run in which ANY beam of this rank has been
+        flagged or removed is refused.  Keep strain_break_limit out of reach in multi-GPU scenes (bench.py does).
+        Also stated, not checkable here: a contact between particles of two NON-adjacent slabs of a folded body is
+        missed (each rank only knows its neighbours' ghost zones)."""
+        _, beams = self.engine.counts()
+        if beams != self.beams_at_start:
+            raise RuntimeError("halo run with broken beams (%d of %d left on rank %d): break flags are not exchanged between "
+                               "ranks; keep strain_break_limit out of reach" % (beams, self.beams_at_start, self.plan.rank))
+        if self.engine.info("beams_flagged"):
+            raise RuntimeError("halo run with beams flagged for deletion on rank %d: break flags are not exchanged between "
+                               "ranks; keep strain_break_limit out of reach" % self.plan.rank)
 
     def exchange(self):
         if not self.plan.peers:
@@ -199,6 +216,7 @@ class PeerExchanger(Exchanger):
         self.engine, self.plan, self.transport = engine, plan, None
         self.since = 0
         self.timeout_ms = timeout_ms
+        self.beams_at_start = engine.counts()[1]
         gp, sp, gb, sb_ = plan.lists()
         engine.halo_configure(gp, sp, gb, sb_)
         self.segs, n_send, n_recv, offsets = plan.segments()
@@ -210,6 +228,13 @@ class PeerExchanger(Exchanger):
         self.connected = False
 
     def connect(self, cards):
+        # HIP multiplexes a process's streams onto 4 hardware queues and a polling kernel blocks whatever is queued
+        # behind it: with more than 3 engines of ONE process wired together a wait kernel can end up in front of the
+        # kernel it waits for (gpurun_out/slabs.log, round 1).  Refused here, with the reason, instead of a timeout later.
+        same = [c for c in cards if c is not None and c["pid"] == self.card["pid"]]
+        if len(same) > 3 and hasattr(self.engine, "stream"):   # (CPU test doubles have no streams and no such limit)
+            raise ValueError("%d engines of one process wired by sb_peer_*: at most 3 (HIP's 4 hardware queues); "
+                             "use one process per engine, the deployment shape" % len(same))
         boxes, rfl, sbeg, slen, dbeg, slot = [], [], [], [], [], []
         for s in self.segs:
             them = cards[s["rank"]]

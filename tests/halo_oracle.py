@@ -14,6 +14,14 @@ class OracleRank:
     def step(self, n):
         self.ref.step(n)
 
+    def counts(self):
+        md = self.ref.metadata.view("<u4")
+        return int(md[1]), int(md[6])       # particle_i_c, beam_i_c (engineMapping.ts:255-256)
+
+    def info(self, key):
+        assert key == "beams_flagged"
+        return int(sum(bin(int(w)).count("1") for w in self.ref.delete))
+
     def halo_configure(self, gp, sp, gb, sb_):
         self.gp, self.sp, self.gb, self.sb = [np.asarray(x, dtype=np.int64) for x in (gp, sp, gb, sb_)]
         self.halo_set_layout(6 * np.arange(self.sp.size), 6 * self.sp.size + 2 * np.arange(self.sb.size),

@@ -1,0 +1,93 @@
+"""The two device-side spin-waits (the device-wide barrier of the hash build, the flag wait of the peer exchange)
+and the limits of the multi-GPU path, exercised on purpose: every one of them must end in a reported status, never
+in a hung wave or a silently wrong result."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_grid_barrier_timeout_is_reported_and_the_engine_recovers(sb):
+    env = dict(os.environ, SB_MAINTAIN_BLOCKS="2048", GRAFT_REPO_ROOT=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "grid_barrier_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and "REPORTED:" in p.stdout and "RECOVERED_OK" in p.stdout, p.stdout + p.stderr
+
+
+def slabs(sb, world, depth=4, strain_limit=1e9, velocity=(0.3, -4.0)):
+    made = []
+    for r in range(world):
+        buf, plan = sb.halo.slab_scene(sb, r, world, 24, 30, depth=depth, d=30.0, origin=(100.0, 11.5), jitter=1.0,
+                                       velocity=velocity, strain_limit=strain_limit)
+        eng = sb.Engine(bounds_size=8000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                        collision_mode=0, path=2, tile_particles=256)
+        eng.write_buffers(buf)
+        made.append((buf, plan, eng))
+    return made
+
+
+def test_four_engines_of_one_process_are_refused_not_timed_out(sb):
+    made = slabs(sb, 4)
+    exs = [sb.halo.PeerExchanger(e, plan, timeout_ms=2000) for _, plan, e in made]
+    cards = [ex.card for ex in exs]
+    with pytest.raises(ValueError, match="at most 3"):
+        exs[0].connect(cards)
+    for _, _, e in made:
+        e.destroy()
+
+
+def test_reconnecting_a_used_mailbox_is_refused(sb):
+    made = slabs(sb, 2)
+    exs = [sb.halo.PeerExchanger(e, plan, timeout_ms=2000) for _, plan, e in made]
+    cards = [ex.card for ex in exs]
+    for ex in exs:
+        ex.connect(cards)
+    for ex in exs:
+        ex.step(4)
+    for _, _, e in made:
+        e.sync()
+    with pytest.raises(sb.engine.EngineError, match="already exchanged"):
+        exs[0].connect(cards)
+    # configuring the halo again on a live mailbox is refused as well; a fresh upload starts over
+    with pytest.raises(sb.engine.EngineError, match="upload again"):
+        made[0][2].halo_configure([], [], [], [])
+    buf, plan, eng = made[0]
+    eng.write_buffers(buf)
+    again = sb.halo.PeerExchanger(eng, plan, timeout_ms=2000)
+    assert again.card["recv_floats"] == exs[0].card["recv_floats"]
+    for _, _, e in made:
+        e.destroy()
+
+
+def test_halo_run_with_broken_beams_is_refused(sb):
+    """Break flags are not exchanged between ranks: a halo run in which a beam broke must say so."""
+    made = slabs(sb, 2, strain_limit=0.02, velocity=(-60.0, -50.0))
+    exs = [sb.halo.PeerExchanger(e, plan, timeout_ms=2000) for _, plan, e in made]
+    cards = [ex.card for ex in exs]
+    for ex in exs:
+        ex.connect(cards)
+    for _ in range(40):
+        for ex in exs:
+            ex.step(4)
+    with pytest.raises(RuntimeError, match="break flags are not exchanged"):
+        for ex in exs:
+            ex.verify()
+    for _, _, e in made:
+        e.destroy()
+    # ... and a run without breaks passes the same check
+    made = slabs(sb, 2)
+    exs = [sb.halo.PeerExchanger(e, plan, timeout_ms=2000) for _, plan, e in made]
+    cards = [ex.card for ex in exs]
+    for ex in exs:
+        ex.connect(cards)
+    for ex in exs:
+        ex.step(4)
+    for ex in exs:
+        ex.verify()
+    for _, _, e in made:
+        e.destroy()
