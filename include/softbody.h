@@ -205,6 +205,38 @@ sb_status sb_peer_connect(sb_engine *e, uint32_t n_peers, void *const *mailboxes
                           const uint32_t *their_slot, uint32_t timeout_ms);
 sb_status sb_peer_exchange(sb_engine *e);
 
+/* ---- generic x-slab partition of ANY scene into per-rank scenes with ghost zones (host only, no GPU needed) ----
+ * The reference has no counterpart (one browser tab, one GPU); this is what lets a scene built by BufferMapper
+ * (engineMapping.ts:432-527) or loaded from a snapshot (:407-430) run on several GPUs.  Input: the four host
+ * buffers of sb_write_buffers.  owner(particle) = equal-population slab of its x coordinate; ghosts of a rank =
+ * everything within `depth` beam hops of its own particles and (contact_reach > 0) of every particle whose x lies
+ * within contact_reach of the x range of its own particles (so that contacts across slab faces are computed on
+ * both sides: choose at least depth * max(2r + the distance a particle moves in one substep, the longest beam)).  Every rank's scene keeps
+ * the relative order of slots and of data indices, so the collision loop's slot order and its index tie-break
+ * (compute.wgsl:144,153) are those of the whole scene.  owner(beam) = owner of its endpoint A.  Exchange every
+ * `depth` substeps (sb_halo_* / sb_peer_*): both sides list the traded records in ascending GLOBAL data index.
+ * Errors are reported through sb_last_error(NULL).  Limits: ghost zones are redundant computation, valid while
+ * information travels at most one hop per substep -- contacts between particles of slabs that are not neighbours
+ * in x are missed, and break flags do not cross ranks. */
+typedef struct sb_partition sb_partition;
+sb_status sb_partition_create(uint32_t layout, uint32_t max_particles, uint32_t max_beams, const void *metadata, const void *mapping,
+                              const void *particles, const void *beams, uint32_t world, uint32_t depth, float contact_reach,
+                              sb_partition **out);
+sb_status sb_partition_destroy(sb_partition *p);
+/* counts = { local particles, local beams, owned particles, owned beams, peers, depth, global particles, global beams } */
+sb_status sb_partition_rank_counts(const sb_partition *p, uint32_t rank, uint32_t counts[8]);
+/* the rank's scene in the partition's layout, into caller buffers of the given capacities (>= the local counts) */
+sb_status sb_partition_rank_scene(const sb_partition *p, uint32_t rank, uint32_t max_particles, uint32_t max_beams, void *metadata,
+                                  void *mapping, void *particles, void *beams);
+/* per LOCAL data index: the global data index and whether this rank owns it (any pointer may be NULL) */
+sb_status sb_partition_rank_ids(const sb_partition *p, uint32_t rank, uint32_t *particle_global, uint8_t *particle_owned,
+                                uint32_t *beam_global, uint8_t *beam_owned);
+/* peer j (ascending rank): its rank and the lengths { ghost particles, sent particles, ghost beams, sent beams } ... */
+sb_status sb_partition_peer_counts(const sb_partition *p, uint32_t rank, uint32_t j, uint32_t *peer_rank, uint32_t counts[4]);
+/* ... and the lists themselves, LOCAL data indices in the order sb_halo_configure expects (any pointer may be NULL) */
+sb_status sb_partition_peer_lists(const sb_partition *p, uint32_t rank, uint32_t j, uint32_t *ghost_particles, uint32_t *send_particles,
+                                  uint32_t *ghost_beams, uint32_t *send_beams);
+
 /* the engine's hipStream_t, so a caller can order its own work (RCCL send/recv) after it. */
 sb_status sb_get_stream(sb_engine *e, void **hip_stream);
 

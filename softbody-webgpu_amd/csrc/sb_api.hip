@@ -17,6 +17,7 @@
 extern "C" sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *);
 
 static thread_local std::string g_create_error;
+void sb_set_create_error(const char *msg) { g_create_error = msg ? msg : ""; } // for sb_partition.cpp
 
 #define SB_FAIL(e, code, ...)                                   \
     do {                                                        \

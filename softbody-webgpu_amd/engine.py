@@ -97,6 +97,14 @@ def load_library():
     L.sb_peer_exchange.argtypes = [vp]
     L.sb_halo_unpack.argtypes = [vp, vp]
     L.sb_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    f32 = ctypes.c_float
+    L.sb_partition_create.argtypes = [u32, u32, u32, vp, vp, vp, vp, u32, u32, f32, ctypes.POINTER(vp)]
+    L.sb_partition_destroy.argtypes = [vp]
+    L.sb_partition_rank_counts.argtypes = [vp, u32, ctypes.POINTER(u32 * 8)]
+    L.sb_partition_rank_scene.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp]
+    L.sb_partition_rank_ids.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.sb_partition_peer_counts.argtypes = [vp, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32 * 4)]
+    L.sb_partition_peer_lists.argtypes = [vp, u32, u32, vp, vp, vp, vp]
     L.sb_last_error.argtypes = [vp]
     L.sb_last_error.restype = ctypes.c_char_p
     L.sb_abi_version.restype = u32

@@ -134,6 +134,50 @@ def slab_scene(sb, rank, world, W, H, d=30.0, origin=(1000.0, 1000.0), jitter=0.
     return buf, plan
 
 
+def partition_scene(buf, world, depth, contact_reach=0.0, ranks=None):
+    """Split ANY scene (a layout.Buffers: the default scene, a loaded snapshot, something a BufferMapper built) into
+    x-slabs with ghost zones `depth` beam hops deep: the C library's sb_partition_* (csrc/sb_partition.cpp), shared
+    with the Node host.  contact_reach > 0 also makes every particle within that distance (in x) of a rank's own
+    particles a ghost, so that contacts across slab faces are computed on both sides.  Returns [(Buffers, HaloPlan)]
+    for `ranks` (default: all).  global_particle_id / global_beam_key of the plans are GLOBAL DATA INDICES."""
+    import ctypes
+    from .engine import EngineError, _ptr, load_library
+    L = load_library()
+    h = ctypes.c_void_p()
+
+    def check(st):
+        if st != 0:
+            raise EngineError(st, L.sb_last_error(None).decode())
+
+    check(L.sb_partition_create(buf.layout, buf.max_particles, buf.max_beams, _ptr(buf.metadata), _ptr(buf.mapping),
+                                _ptr(buf.particles), _ptr(buf.beams), world, depth, float(contact_reach), ctypes.byref(h)))
+    try:
+        out = []
+        for r in (range(world) if ranks is None else ranks):
+            c = (ctypes.c_uint32 * 8)()
+            check(L.sb_partition_rank_counts(h, r, ctypes.byref(c)))
+            nP, nB, n_peers = c[0], c[1], c[4]
+            local = Buffers(buf.layout, max(nP, 1), max(nB, 1))
+            check(L.sb_partition_rank_scene(h, r, local.max_particles, local.max_beams, _ptr(local.metadata), _ptr(local.mapping),
+                                            _ptr(local.particles), _ptr(local.beams)))
+            pg, po = np.zeros(nP, "<u4"), np.zeros(nP, "u1")
+            bg, bo = np.zeros(nB, "<u4"), np.zeros(nB, "u1")
+            check(L.sb_partition_rank_ids(h, r, _ptr(pg), _ptr(po), _ptr(bg), _ptr(bo)))
+            peers = []
+            for j in range(n_peers):
+                pr, pc = ctypes.c_uint32(), (ctypes.c_uint32 * 4)()
+                check(L.sb_partition_peer_counts(h, r, j, ctypes.byref(pr), ctypes.byref(pc)))
+                lists = [np.zeros(pc[k], "<u4") for k in range(4)]
+                check(L.sb_partition_peer_lists(h, r, j, *[_ptr(x) for x in lists]))
+                peers.append(Peer(pr.value, *lists))
+            plan = HaloPlan(r, world, depth if world > 1 else 0, nP, np.nonzero(po)[0].astype("<u4"),
+                            np.nonzero(bo)[0].astype("<u4"), peers, pg.astype(np.int64), bg.astype(np.int64))
+            out.append((local, plan))
+        return out
+    finally:
+        L.sb_partition_destroy(h)
+
+
 def mix_stiffness(buf, plan, seed=1, subticks=128):
     """scenes.mix_stiffness for slab scenes (BASELINE config 5 across ranks): the draw is keyed by the GLOBAL
     beam key, so a ghost copy of a beam gets exactly its owner's spring and damping."""
