@@ -124,5 +124,39 @@ const same = (ab, file) => Buffer.compare(Buffer.from(ab), fs.readFileSync(path.
         assert.deepStrictEqual(px(92, 20), [255, 255, 255]);
         assert.deepStrictEqual(px(300, 300), [0, 0, 0]);
     });
+    test('partitionScene: the default scene in two and three x-slabs (C library sb_partition_*, host/halo.js)', () => {
+        const m = h.defaultScene(new h.BufferMapper(1 << 27, { layout: 2, maxParticles: 256, maxBeams: 512 }));
+        m.writeState();
+        for (const world of [2, 3]) {
+            const ranks = h.partitionScene(m, world, 2, 0);
+            assert.strictEqual(ranks.length, world);
+            assert.strictEqual(ranks.reduce((n, r) => n + r.plan.nOwned, 0), 119);
+            assert.strictEqual(ranks.reduce((n, r) => n + r.plan.ownedBeams.length, 0), 299);
+            const seen = new Set();
+            for (const r of ranks) {
+                for (const i of r.plan.ownedParticles) { assert.ok(!seen.has(r.plan.globalParticleId[i])); seen.add(r.plan.globalParticleId[i]); }
+                const md = new Uint32Array(r.metadata);
+                assert.strictEqual(md[1], r.plan.nLocal);
+                assert.strictEqual(md[10], r.maxParticles);
+                for (const peer of r.plan.peers) {
+                    const back = ranks[peer.rank].plan.peers.filter((q) => q.rank === r.rank)[0];
+                    // what I hold as ghosts is what the owner sends, in the same order, and starts out bit-identical
+                    assert.deepStrictEqual(Array.from(peer.ghostP).map((i) => r.plan.globalParticleId[i]),
+                        Array.from(back.sendP).map((i) => ranks[peer.rank].plan.globalParticleId[i]));
+                    assert.deepStrictEqual(Array.from(peer.ghostB).map((i) => r.plan.globalBeamKey[i]),
+                        Array.from(back.sendB).map((i) => ranks[peer.rank].plan.globalBeamKey[i]));
+                    const mine = new Float32Array(r.particleData), theirs = new Float32Array(ranks[peer.rank].particleData);
+                    peer.ghostP.forEach((i, k) => assert.strictEqual(mine[6 * i], theirs[6 * back.sendP[k]]));
+                }
+                const lay = r.plan.segments();
+                assert.strictEqual(lay.offsets[2].length, r.plan.lists()[0].length);
+            }
+            assert.strictEqual(seen.size, 119);
+        }
+        assert.throws(() => h.partitionScene(m, 2, 0, 0), /depth 0/);
+        const a = h.native();
+        for (const f of ['haloConfigure', 'haloSetLayout', 'peerMailbox', 'peerMap', 'peerConnect', 'peerExchange', 'getStream'])
+            assert.strictEqual(typeof a[f], 'function', f);
+    });
     console.log(JSON.stringify({ passed: results.length, failed: process.exitCode ? 1 : 0, names: results }));
 })();

@@ -39,6 +39,12 @@ const rd = (f) => { const b = fs.readFileSync(path.join(GOLDEN, f)); return b.bu
     assert.strictEqual(w.bufferMapper.beamSet.size, 2945);
     const p0 = w.bufferMapper.findParticle(0);
     assert.ok(p0.position.y < 100 && p0.position.y >= 10, 'lattice fell: ' + p0.position.y);
+    // ... and byte for byte the oracle's state after the same 1000 substeps (tests/golden/make_golden.py)
+    const gold = JSON.parse(fs.readFileSync(path.join(GOLDEN, 'lattice_32x32_after_1000_substeps.json'), 'utf8'));
+    const lsnap = Buffer.from(w.bufferMapper.createSnapshotBuffer());
+    assert.strictEqual(lsnap.length, gold.bytes);
+    assert.deepStrictEqual([p0.position.x, p0.position.y, p0.velocity.x, p0.velocity.y], gold.first_particle.slice(0, 4));
+    assert.strictEqual(require('crypto').createHash('sha256').update(lsnap).digest('hex'), gold.sha256, 'config-1 lattice after 1000 substeps differs from the oracle golden');
     const info = { tiles: w.addon.getInfo(w.handle, 'tiles'), path: w.addon.getInfo(w.handle, 'path') };
     await w.destroy();
     await engine.destroy();

@@ -13,6 +13,10 @@ browser's WebGPU only) and ships no recorded outputs, so these vectors are produ
       (oracle/sb_oracle.c, S0 semantics).  Parity against the real WebGPU engine is "unpinned".
   lattice_8x6_after_100_substeps.npz
       a small jittered lattice (v2 layout, collisions off) before/after 100 oracle substeps.
+  lattice_32x32_after_1000_substeps.json
+      BASELINE config 1 (32 x 32 lattice of main.ts:220's material at (100, 100), spacing 25, collisions off,
+      v2 layout): SHA-256 of the v2 snapshot after 1000 oracle substeps, its length, and the first and last particle
+      records, for host/test/gpu.test.js (the whole Node path must reproduce the snapshot byte for byte).
 """
 import os
 import sys
@@ -48,6 +52,19 @@ def main():
     np.savez_compressed(os.path.join(HERE, "lattice_8x6_after_100_substeps.npz"),
                         particles_in=lat.particles, beams_in=lat.beams.view("u1"),
                         particles_out=out.particles, beams_out=out.beams.view("u1"))
+    import hashlib
+    import json
+    lat = sb.scenes.lattice_buffers(32, 32, d=25.0, origin=(100.0, 100.0), spring=50.0, damp=700.0, yield_strain=0.2,
+                                    strain_limit=0.5, layout=2)
+    ref = orc.OracleEngine(1000.0, 10.0, 64, 2, orc.COLLIDE_OFF)
+    ref.write_buffers(lat)
+    ref.step(1000)
+    out = ref.load_buffers(lat.copy())
+    snap = out.create_snapshot()
+    json.dump({"sha256": hashlib.sha256(snap).hexdigest(), "bytes": len(snap), "particles": out.particle_count,
+               "beams": out.beam_count, "first_particle": [float(x) for x in out.particles[0]],
+               "last_particle": [float(x) for x in out.particles[out.particle_count - 1]]},
+              open(os.path.join(HERE, "lattice_32x32_after_1000_substeps.json"), "w"), indent=1)
     print("golden fixtures written to", HERE)
 
 

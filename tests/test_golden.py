@@ -57,3 +57,38 @@ def test_gpu_hits_goldens_without_oracle(sb):
         eng.destroy()
         assert np.array_equal(out.particles.view("u4"), z["particles_out"].view("u4"))
         assert np.array_equal(out.beams.view("u1"), z["beams_out"])
+
+
+def config1_lattice(sb):
+    return sb.scenes.lattice_buffers(32, 32, d=25.0, origin=(100.0, 100.0), spring=50.0, damp=700.0, yield_strain=0.2,
+                                     strain_limit=0.5, layout=2)
+
+
+def test_oracle_reproduces_the_config1_golden(sb, oracle):
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(GOLDEN, "lattice_32x32_after_1000_substeps.json")))
+    lat = config1_lattice(sb)
+    ref = oracle.OracleEngine(1000.0, 10.0, 64, 2, oracle.COLLIDE_OFF)
+    ref.write_buffers(lat)
+    ref.step(1000)
+    snap = ref.load_buffers(lat.copy()).create_snapshot()
+    assert len(snap) == gold["bytes"] and hashlib.sha256(snap).hexdigest() == gold["sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path,block", [(1, 0), (2, 1), (2, 0)])
+def test_gpu_hits_the_config1_golden_without_oracle(sb, path, block):
+    """BASELINE config 1 (32 x 32 lattice, 1000 substeps): atomic schedule, single-substep tiles, blocked tiles."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(GOLDEN, "lattice_32x32_after_1000_substeps.json")))
+    lat = config1_lattice(sb)
+    eng = sb.Engine(layout=2, max_particles=lat.max_particles, max_beams=lat.max_beams, collision_mode=0, path=path,
+                    tile_particles=256, block_substeps=block)
+    eng.write_buffers(lat)
+    eng.step(1000)
+    out = eng.load_buffers(lat.copy())
+    eng.destroy()
+    assert [float(x) for x in out.particles[0]] == gold["first_particle"]
+    assert hashlib.sha256(out.create_snapshot()).hexdigest() == gold["sha256"]

@@ -28,7 +28,7 @@ def test_js_host_cpu():
     loud failure without a GPU."""
     import torch
     r = run_node("cpu.test.js", {"SOFTBODY_EXPECT_NO_GPU": "0" if torch.cuda.is_available() else "1"})
-    assert r["failed"] == 0 and r["passed"] == 10
+    assert r["failed"] == 0 and r["passed"] == 11
 
 
 @needs_node
@@ -52,3 +52,13 @@ def test_js_bench_small():
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["particles"] == 64 * 48 and r["info"]["path"] == 2 and r["particle_steps_per_s_device"] > 0
     assert r["first_particle_y"] < 1000.0
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_two_processes_trade_ghost_zones():
+    """Multi-GPU from the product host: two `node` processes, each driving its own engine on its slab of one scene
+    (host/halo.js partitionScene + PeerExchanger over the N-API bindings of sb_partition_* / sb_halo_* / sb_peer_*),
+    trading ghost zones through IPC-mapped mailboxes on one GPU; together bit-identical to the single engine."""
+    r = run_node("halo.gpu.test.js", timeout=600)
+    assert r["ok"] and r["particles"] == 1440 and r["exchanges"] == 24 and min(r["ghosts"]) > 0
