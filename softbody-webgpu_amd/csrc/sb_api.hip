@@ -4,7 +4,10 @@
 // upload / read-back), minus the canvas/render/Worker plumbing.  No CPU fallback: every entry
 // point needs a live HIP device and fails loudly otherwise.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -55,6 +58,20 @@ static sb_status dev_alloc(sb_engine *e, T **p, size_t n)
         sb_status _s = (x);                \
         if (_s != SB_OK) return _s;        \
     } while (0)
+
+// SB_UPLOAD_TIMING=1: where sb_write_buffers spends its time (stderr), for tuning the host side of an upload
+struct SbStageTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    SbStageTimer() : on(getenv("SB_UPLOAD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sb upload] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 static void free_scene(sb_engine *e)
 {
@@ -118,12 +135,18 @@ static void build_material_dictionary(SbMatDict &d, const std::vector<SbHostBeam
     for (int mode = 2; mode >= 1 && cap; mode--) {
         std::unordered_map<Key, uint32_t, KeyHash> dict;
         std::vector<float> table;
-        bool ok = true;
+        bool ok = true, have_last = false;
+        Key last_key{};
+        uint32_t last_row = 0;
         for (uint32_t s = 0; s < B && ok; s++) {
             Key k;
             const float *f = hb[s].f; // length, target, last, spring, damp, yield, limit
             float row[5] = {mode == 2 ? f[0] : 0.0f, f[3], f[4], f[5], f[6]};
             memcpy(k.w, row, sizeof row);
+            if (have_last && k == last_key) { // runs of one material are the rule: no hash lookup
+                d.of_slot[s] = last_row;
+                continue;
+            }
             auto it = dict.find(k);
             if (it == dict.end()) {
                 if (dict.size() >= cap) { ok = false; break; }
@@ -132,6 +155,9 @@ static void build_material_dictionary(SbMatDict &d, const std::vector<SbHostBeam
                 table.push_back(mode == 2 ? 1.0f / row[0] : 0.0f); // 1 / length: one IEEE divide per material
             }
             d.of_slot[s] = it->second;
+            last_key = k;
+            last_row = it->second;
+            have_last = true;
         }
         if (ok) {
             d.mode = (uint32_t)mode;
@@ -182,11 +208,13 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
     std::vector<uint32_t> words(bl.ent_la.size());
     std::vector<float> lengths;
     if (md.mode == 1) lengths.resize(words.size());
-    for (size_t j = 0; j < words.size(); j++) {
-        const uint32_t s = bl.ent_slot[j];
-        words[j] = bl.ent_la[j] | (bl.ent_lb[j] << SB_BK_LBITS) | (md.of_slot[s] << (2u * SB_BK_LBITS));
-        if (md.mode == 1) lengths[j] = hb[s].f[0];
-    }
+    sbt::parallel_ranges(words.size(), 1 << 16, [&](size_t j0, size_t j1) {
+        for (size_t j = j0; j < j1; j++) {
+            const uint32_t s = bl.ent_slot[j];
+            words[j] = bl.ent_la[j] | (bl.ent_lb[j] << SB_BK_LBITS) | (md.of_slot[s] << (2u * SB_BK_LBITS));
+            if (md.mode == 1) lengths[j] = hb[s].f[0];
+        }
+    });
     SB_TRY(dev_upload(e, &k.d_tile_p0, bl.tile_p0));
     SB_TRY(dev_upload(e, &k.d_tile_h0, bl.tile_h0));
     SB_TRY(dev_upload(e, &k.d_halo_idx, bl.halo_idx));
@@ -209,7 +237,9 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
     float **dst[4] = {&k.d_target[0], &k.d_last[0], &e->beams.strain, &e->beams.stress};
     const int field[4] = {1, 2, 7, 8};
     for (int a = 0; a < 4; a++) {
-        for (uint32_t g = 0; g < B; g++) tmp[g] = hb[bl.beam_slot[g]].f[field[a]];
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t g0, size_t g1) {
+            for (size_t g = g0; g < g1; g++) tmp[g] = hb[bl.beam_slot[g]].f[field[a]];
+        });
         SB_TRY(dev_upload(e, dst[a], tmp));
     }
     SB_TRY(dev_alloc(e, &k.d_target[1], B));
@@ -341,6 +371,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     SB_HIP(e, hipStreamSynchronize(e->stream));
     free_scene(e);
 
+    SbStageTimer tm;
     // ---- host shadows (copy semantics)
     e->h_metadata.assign(md, md + SB_METADATA_BYTES);
     e->h_mapping.assign(mp, mp + (size_t)(maxP + (size_t)maxB) * map_isz(e));
@@ -349,6 +380,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     e->cur = 0;
     e->substeps_done = 0;
 
+    tm.mark("sync + free + shadows");
     // ---- particles: slot -> data index, must be a partial injection
     std::vector<uint32_t> slot_index(P), internal_of_index(maxP, 0xFFFFFFFFu);
     for (uint32_t s = 0; s < P; s++) {
@@ -362,38 +394,60 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     // ---- beams: slot -> record; endpoints must be active particles
     std::vector<SbHostBeam> hb(B);
     {
+        // a few host threads over the beam slots; the first offence (lowest slot of its chunk) is reported
         std::vector<uint8_t> seen((size_t)maxB, 0);
-        for (uint32_t s = 0; s < B; s++) {
-            uint32_t idx = map_get(e, mp, (size_t)maxP + s);
-            if (idx >= maxB) SB_FAIL(e, SB_ERR_INVALID, "beam slot %u maps to data index %u >= max_beams", s, idx);
-            if (seen[idx]) SB_FAIL(e, SB_ERR_INVALID, "beam data index %u is mapped by two slots", idx);
-            seen[idx] = 1;
-            const uint8_t *rec = bd + (size_t)idx * bstride;
-            uint32_t a, b;
-            const uint8_t *f;
-            if (e->opt.layout == SB_LAYOUT_V1) { // engineMapping.ts:183-186, compute.wgsl:99-100
-                uint32_t pair = rd_u32(rec);
-                a = pair & 0xffffu;
-                b = pair >> 16;
-                f = rec + 4;
-            } else {
-                a = rd_u32(rec);
-                b = rd_u32(rec + 4);
-                f = rec + 8;
+        struct Bad { uint32_t slot = 0xFFFFFFFFu, kind = 0, idx = 0, a = 0, b = 0; };
+        std::vector<Bad> bad(64);
+        std::atomic<uint32_t> nchunk{0};
+        sbt::parallel_ranges(B, 1 << 15, [&](size_t s0, size_t s1) {
+            Bad &mine = bad[nchunk.fetch_add(1) % bad.size()];
+            for (size_t s = s0; s < s1; s++) {
+                const uint32_t idx = map_get(e, mp, (size_t)maxP + s);
+                Bad here;
+                here.slot = (uint32_t)s;
+                here.idx = idx;
+                if (idx >= maxB) here.kind = 1;
+                else if (__atomic_fetch_or(&seen[idx], 1, __ATOMIC_RELAXED)) here.kind = 2;
+                if (!here.kind) {
+                    const uint8_t *rec = bd + (size_t)idx * bstride;
+                    uint32_t a, b;
+                    const uint8_t *f;
+                    if (e->opt.layout == SB_LAYOUT_V1) { // engineMapping.ts:183-186, compute.wgsl:99-100
+                        uint32_t pair = rd_u32(rec);
+                        a = pair & 0xffffu;
+                        b = pair >> 16;
+                        f = rec + 4;
+                    } else {
+                        a = rd_u32(rec);
+                        b = rd_u32(rec + 4);
+                        f = rec + 8;
+                    }
+                    here.a = a;
+                    here.b = b;
+                    if (a >= maxP || b >= maxP || internal_of_index[a] == 0xFFFFFFFFu || internal_of_index[b] == 0xFFFFFFFFu) here.kind = 3;
+                    else {
+                        SbHostBeam &h = hb[s];
+                        h.a = internal_of_index[a]; // slot of endpoint A (re-indexed below)
+                        h.b = internal_of_index[b];
+                        h.da = a;
+                        h.db = b;
+                        memcpy(h.f, f, 9 * sizeof(float));
+                    }
+                }
+                if (here.kind && here.slot < mine.slot) mine = here;
             }
-            if (a >= maxP || b >= maxP || internal_of_index[a] == 0xFFFFFFFFu || internal_of_index[b] == 0xFFFFFFFFu)
-                SB_FAIL(e, SB_ERR_INVALID,
-                        "beam slot %u (data index %u) references particle data index %u/%u that no particle slot maps to",
-                        s, idx, a, b);
-            SbHostBeam &h = hb[s];
-            h.a = internal_of_index[a]; // slot of endpoint A (re-indexed below)
-            h.b = internal_of_index[b];
-            h.da = a;
-            h.db = b;
-            memcpy(h.f, f, 9 * sizeof(float));
-        }
+        });
+        Bad first;
+        for (const Bad &c : bad)
+            if (c.kind && c.slot < first.slot) first = c;
+        if (first.kind == 1) SB_FAIL(e, SB_ERR_INVALID, "beam slot %u maps to data index %u >= max_beams", first.slot, first.idx);
+        if (first.kind == 2) SB_FAIL(e, SB_ERR_INVALID, "beam data index %u is mapped by two slots", first.idx);
+        if (first.kind == 3)
+            SB_FAIL(e, SB_ERR_INVALID, "beam slot %u (data index %u) references particle data index %u/%u that no particle slot maps to",
+                    first.slot, first.idx, first.a, first.b);
     }
 
+    tm.mark("validate + beam records");
     // ---- internal particle order
     std::vector<float> px(P), py(P);
     for (uint32_t s = 0; s < P; s++) {
@@ -431,16 +485,19 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     e->h_pidx.resize(P);
     for (uint32_t i = 0; i < P; i++) e->h_pidx[i] = slot_index[order[i]];
 
+    tm.mark("tiling / blocking plan");
     // ---- upload particles (A = data, B = zero: engineWorker.ts:588,593)
     {
         std::vector<float2> hp(P), hv(P), ha(P);
-        for (uint32_t i = 0; i < P; i++) {
-            float q[6];
-            memcpy(q, pd + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, SB_PARTICLE_STRIDE);
-            hp[i] = make_float2(q[0], q[1]);
-            hv[i] = make_float2(q[2], q[3]);
-            ha[i] = make_float2(q[4], q[5]);
-        }
+        sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                float q[6];
+                memcpy(q, pd + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, SB_PARTICLE_STRIDE);
+                hp[i] = make_float2(q[0], q[1]);
+                hv[i] = make_float2(q[2], q[3]);
+                ha[i] = make_float2(q[4], q[5]);
+            }
+        });
         for (int k = 0; k < 2; k++) {
             SB_TRY(dev_alloc(e, &e->part[k].pos, P));
             SB_TRY(dev_alloc(e, &e->part[k].vel, P));
@@ -458,6 +515,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_HIP(e, hipMemcpy(e->d_pslot, e->h_pslot.data(), P * 4, hipMemcpyHostToDevice));
     }
 
+    tm.mark("particles to device");
     // ---- beam copies
     std::vector<uint32_t> c_ia, c_ib, c_pair, c_slot;
     std::vector<float> mat_table;
@@ -585,6 +643,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             if (nc) SB_HIP(e, hipMemcpy(e->beams.ib, c_ib.data(), nc * 4, hipMemcpyHostToDevice));
         }
     }
+    tm.mark("beams to device");
     // ---- spatial hash: covers the uploaded bounding box plus a margin; particles that later
     // leave it are clamped into edge cells (still a superset of the contacts, sb_physics.h)
     e->grid = SbGrid{};
@@ -672,6 +731,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.nl_stride = P;
         e->grid.ctl = &e->d_grid_ctl[0];
     }
+    tm.mark("spatial hash arrays");
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
     if (e->path == SB_PATH_ATOMIC) {
         SB_TRY(dev_alloc(e, &e->d_forces, P));
@@ -686,6 +746,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     SB_HIP(e, hipDeviceSynchronize());
     e->h_beams.swap(hb);
     e->loaded = true;
+    tm.mark("masks + final sync");
     return SB_OK;
 }
 
@@ -865,10 +926,12 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
         SB_HIP(e, hipMemcpy(hv.data(), c.vel, P * sizeof(float2), hipMemcpyDeviceToHost));
         SB_HIP(e, hipMemcpy(ha.data(), c.acc, P * sizeof(float2), hipMemcpyDeviceToHost));
         uint8_t *out = (uint8_t *)particles;
-        for (uint32_t i = 0; i < P; i++) {
-            float q[6] = {hp[i].x, hp[i].y, hv[i].x, hv[i].y, ha[i].x, ha[i].y};
-            memcpy(out + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, q, SB_PARTICLE_STRIDE);
-        }
+        sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                float q[6] = {hp[i].x, hp[i].y, hv[i].x, hv[i].y, ha[i].x, ha[i].y};
+                memcpy(out + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, q, SB_PARTICLE_STRIDE);
+            }
+        });
     }
     if (beams && B) {
         const uint32_t nc = e->nbeam;
@@ -879,7 +942,8 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
         SB_HIP(e, hipMemcpy(ss.data(), e->beams.stress, nc * 4, hipMemcpyDeviceToHost));
         uint8_t *out = (uint8_t *)beams;
         const size_t foff = e->opt.layout == SB_LAYOUT_V1 ? 4 : 8;
-        for (uint32_t s = 0; s < B; s++) {
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
+        for (size_t s = s0; s < s1; s++) {
             // every slot that was active at upload is written, dead ones with their last state
             uint32_t c = e->h_copy_of_slot[s];
             uint32_t idx = map_get(e, e->h_mapping.data(), (size_t)maxP + s);
@@ -898,6 +962,7 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
             memcpy(f + 28, &sn[c], 4); // strain
             memcpy(f + 32, &ss[c], 4); // stress
         }
+        });
     }
     return SB_OK;
 }

@@ -21,7 +21,10 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -73,38 +76,48 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
                               const std::vector<SbHostBeam> &beams, uint32_t target, uint32_t K)
 {
     const uint32_t P = (uint32_t)px.size(), B = (uint32_t)beams.size();
+    const bool timing = getenv("SB_UPLOAD_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sb blocking] %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     target = std::max(64u, std::min(target, 16384u));
     t.K = K;
-    t.order.resize(P);
-    for (uint32_t i = 0; i < P; i++) t.order[i] = i;
-    t.tile_p0.assign(1, 0);
-    if (P) {
-        sbt::Splitter sp{px, py, t.order, t.tile_p0, target};
-        sp.split(0, P, (P + target - 1) / target);
-    }
+    sbt::bisect(px, py, t.order, t.tile_p0, target);
     const uint32_t T = t.ntiles = (uint32_t)t.tile_p0.size() - 1;
     std::vector<uint32_t> internal_of_slot(P), tile_of(P);
     for (uint32_t i = 0; i < P; i++) internal_of_slot[t.order[i]] = i;
     for (uint32_t k = 0; k < T; k++)
         for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = k;
 
+    mark("bisection");
     // beam endpoints as internal indices; adjacency (particle -> incident beam slots)
+    // (filled by several threads with atomic cursors: the order inside a particle's list is arbitrary, and nothing below
+    // depends on it -- frontiers and entry lists are sorted after they are collected)
     std::vector<uint32_t> ba(B), bb(B), adj0(P + 1, 0);
-    for (uint32_t s = 0; s < B; s++) {
-        ba[s] = internal_of_slot[beams[s].a];
-        bb[s] = internal_of_slot[beams[s].b];
-        adj0[ba[s] + 1]++;
-        if (bb[s] != ba[s]) adj0[bb[s] + 1]++;
-    }
+    sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
+        for (size_t s = s0; s < s1; s++) {
+            ba[s] = internal_of_slot[beams[s].a];
+            bb[s] = internal_of_slot[beams[s].b];
+            __atomic_fetch_add(&adj0[ba[s] + 1], 1u, __ATOMIC_RELAXED);
+            if (bb[s] != ba[s]) __atomic_fetch_add(&adj0[bb[s] + 1], 1u, __ATOMIC_RELAXED);
+        }
+    });
     for (uint32_t i = 0; i < P; i++) adj0[i + 1] += adj0[i];
     std::vector<uint32_t> adj(adj0[P]);
     {
         std::vector<uint32_t> cur(adj0.begin(), adj0.end() - 1);
-        for (uint32_t s = 0; s < B; s++) {
-            adj[cur[ba[s]]++] = s;
-            if (bb[s] != ba[s]) adj[cur[bb[s]]++] = s;
-        }
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
+            for (size_t s = s0; s < s1; s++) {
+                adj[__atomic_fetch_add(&cur[ba[s]], 1u, __ATOMIC_RELAXED)] = (uint32_t)s;
+                if (bb[s] != ba[s]) adj[__atomic_fetch_add(&cur[bb[s]], 1u, __ATOMIC_RELAXED)] = (uint32_t)s;
+            }
+        });
     }
+    mark("adjacency");
     // Order of the beams inside a tile, for the owned state arrays and for every entry list: by the beam's RANK among
     // the beams that leave its endpoint A (0 = A's first beam in slot order, 1 = its second ...), then by A.  Consecutive
     // lanes of the kernel then work on consecutive particles -- in a lattice "all the +y beams, then all the +x beams,
@@ -123,17 +136,25 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     t.beam_slot.assign(B, 0);
     t.g_of_slot.assign(B, 0);
     {
+        // (keys travel with the elements: a comparator that looks rank[] and ba[] up by slot misses the cache on every compare)
+        struct Key { uint64_t rank_a; uint32_t slot; };
+        std::vector<Key> keyed(B);
         std::vector<uint32_t> cur(t.tile_b0.begin(), t.tile_b0.end() - 1);
-        for (uint32_t s = 0; s < B; s++) t.beam_slot[cur[tile_of[ba[s]]]++] = s;
-        for (uint32_t k = 0; k < T; k++)
-            std::sort(t.beam_slot.begin() + t.tile_b0[k], t.beam_slot.begin() + t.tile_b0[k + 1], [&](uint32_t x, uint32_t y) {
-                if (rank[x] != rank[y]) return rank[x] < rank[y];
-                if (ba[x] != ba[y]) return ba[x] < ba[y];
-                return x < y;
-            });
-        for (uint32_t g = 0; g < B; g++) t.g_of_slot[t.beam_slot[g]] = g;
+        for (uint32_t s = 0; s < B; s++) keyed[cur[tile_of[ba[s]]]++] = Key{((uint64_t)rank[s] << 32) | ba[s], s};
+        sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; k++)
+                std::sort(keyed.begin() + t.tile_b0[k], keyed.begin() + t.tile_b0[k + 1],
+                          [](const Key &x, const Key &y) { return x.rank_a != y.rank_a ? x.rank_a < y.rank_a : x.slot < y.slot; });
+        });
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t g0, size_t g1) {
+            for (size_t g = g0; g < g1; g++) {
+                t.beam_slot[g] = keyed[g].slot;
+                t.g_of_slot[keyed[g].slot] = (uint32_t)g;
+            }
+        });
     }
 
+    mark("owned beams");
     // per tile: rings, region, entries (tiles are independent: a few host threads)
     struct TileOut {
         std::vector<uint32_t> halo, ring_cnt, la, lb, slot, lvl_cnt, state, nb;
@@ -143,7 +164,7 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
         std::vector<uint32_t> stamp(P, 0xFFFFFFFFu), local(P, 0);
         std::vector<uint8_t> ring(P, 0);
         std::vector<uint32_t> frontier, next;
-        struct Ent { uint32_t m, owned, slot; };
+        struct Ent { uint64_t key; uint32_t a, slot, m; }; // key = (smaller ring, not-owned, rank): the sort order, carried along
         std::vector<Ent> ents;
         for (uint32_t k = k0; k < k1; k++) {
             TileOut &o = out[k];
@@ -188,17 +209,15 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
                     if (p == a ? true : !a_emits) {
                         if (p != a && p != b) continue;
                         const uint32_t m = std::min<uint32_t>(ring[a], ring[b]);
-                        ents.push_back(Ent{m, tile_of[a] == k ? 0u : 1u, s});
+                        ents.push_back(Ent{((uint64_t)m << 40) | ((uint64_t)(tile_of[a] == k ? 0u : 1u) << 32) | rank[s], a, s, m});
                     }
                 }
             };
             for (uint32_t i = p0; i < p1; i++) visit(i);
             for (uint32_t q : o.halo) visit(q);
-            std::sort(ents.begin(), ents.end(), [&](const Ent &x, const Ent &y) {
-                if (x.m != y.m) return x.m < y.m;
-                if (x.owned != y.owned) return x.owned < y.owned;
-                if (rank[x.slot] != rank[y.slot]) return rank[x.slot] < rank[y.slot];
-                if (ba[x.slot] != ba[y.slot]) return ba[x.slot] < ba[y.slot];
+            std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) {
+                if (x.key != y.key) return x.key < y.key;
+                if (x.a != y.a) return x.a < y.a;
                 return x.slot < y.slot;
             });
             const size_t n = ents.size();
@@ -212,7 +231,7 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
                 o.la[j] = local[ba[s]];
                 o.lb[j] = local[bb[s]];
                 o.slot[j] = s;
-                if (ents[j].owned) o.state.push_back(t.g_of_slot[s]);
+                if ((ents[j].key >> 32) & 1u) o.state.push_back(t.g_of_slot[s]);
                 for (uint32_t m = ents[j].m; m < K; m++) o.lvl_cnt[m]++;
             }
             // tiles that own my halo particles (their acceleration flags decide whether halo a's are read)
@@ -223,6 +242,7 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
         }
     });
 
+    mark("rings + entries per tile");
     t.tile_h0.assign(T + 1, 0);
     t.tile_e0.assign(T + 1, 0);
     t.tile_s0.assign(T + 1, 0);
@@ -248,22 +268,29 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     t.ent_state.resize(t.tile_s0[T]);
     t.tile_nb.resize(t.tile_n0[T]);
     t.slot_e0.assign(B + 1, 0);
-    for (uint32_t k = 0; k < T; k++) {
-        const TileOut &o = out[k];
-        std::copy(o.halo.begin(), o.halo.end(), t.halo_idx.begin() + t.tile_h0[k]);
-        std::copy(o.ring_cnt.begin(), o.ring_cnt.end(), t.ring_cnt.begin() + (size_t)k * (K + 1));
-        std::copy(o.lvl_cnt.begin(), o.lvl_cnt.end(), t.lvl_cnt.begin() + (size_t)k * K);
-        std::copy(o.la.begin(), o.la.end(), t.ent_la.begin() + t.tile_e0[k]);
-        std::copy(o.lb.begin(), o.lb.end(), t.ent_lb.begin() + t.tile_e0[k]);
-        std::copy(o.slot.begin(), o.slot.end(), t.ent_slot.begin() + t.tile_e0[k]);
-        std::copy(o.state.begin(), o.state.end(), t.ent_state.begin() + t.tile_s0[k]);
-        std::copy(o.nb.begin(), o.nb.end(), t.tile_nb.begin() + t.tile_n0[k]);
-        for (uint32_t s : o.slot) t.slot_e0[s + 1]++;
-    }
+    sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            const TileOut &o = out[k];
+            std::copy(o.halo.begin(), o.halo.end(), t.halo_idx.begin() + t.tile_h0[k]);
+            std::copy(o.ring_cnt.begin(), o.ring_cnt.end(), t.ring_cnt.begin() + (size_t)k * (K + 1));
+            std::copy(o.lvl_cnt.begin(), o.lvl_cnt.end(), t.lvl_cnt.begin() + (size_t)k * K);
+            std::copy(o.la.begin(), o.la.end(), t.ent_la.begin() + t.tile_e0[k]);
+            std::copy(o.lb.begin(), o.lb.end(), t.ent_lb.begin() + t.tile_e0[k]);
+            std::copy(o.slot.begin(), o.slot.end(), t.ent_slot.begin() + t.tile_e0[k]);
+            std::copy(o.state.begin(), o.state.end(), t.ent_state.begin() + t.tile_s0[k]);
+            std::copy(o.nb.begin(), o.nb.end(), t.tile_nb.begin() + t.tile_n0[k]);
+        }
+    });
+    sbt::parallel_ranges(E, 1 << 16, [&](size_t e0, size_t e1) {
+        for (size_t e = e0; e < e1; e++) __atomic_fetch_add(&t.slot_e0[t.ent_slot[e] + 1], 1u, __ATOMIC_RELAXED);
+    });
     for (uint32_t s = 0; s < B; s++) t.slot_e0[s + 1] += t.slot_e0[s];
     t.slot_ent.resize(E);
     {
         std::vector<uint32_t> cur(t.slot_e0.begin(), t.slot_e0.end() - 1);
-        for (uint32_t e = 0; e < E; e++) t.slot_ent[cur[t.ent_slot[e]]++] = e;
+        sbt::parallel_ranges(E, 1 << 16, [&](size_t e0, size_t e1) {
+            for (size_t e = e0; e < e1; e++) t.slot_ent[__atomic_fetch_add(&cur[t.ent_slot[e]], 1u, __ATOMIC_RELAXED)] = (uint32_t)e;
+        });
     }
+    mark("merge + slot->entries");
 }

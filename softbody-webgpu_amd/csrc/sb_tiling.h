@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 struct SbHostBeam {
@@ -37,20 +38,37 @@ struct SbTiling {
 
 namespace sbt {
 
+// f(begin, end) over [0, n) in contiguous chunks on a few host threads (uploads of millions of records)
+template <typename F>
+inline void parallel_ranges(size_t n, size_t min_chunk, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 4u, 16u), n / std::max<size_t>(min_chunk, 1)));
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t w = 0; w < nt; w++) th.emplace_back([=, &f] { f(n * w / nt, n * (w + 1) / nt); });
+    for (auto &t : th) t.join();
+}
+
 struct Splitter {
     const std::vector<float> &x, &y;
     std::vector<uint32_t> &order;
-    std::vector<uint32_t> &tile_p0;
+    std::vector<uint32_t> &tile_p0; // [tiles + 1], sized by the caller; tile_p0[0] = 0
     uint32_t target;
 
     static float key(float v) { return std::isfinite(v) ? v : 0.0f; }
 
-    void split(uint32_t lo, uint32_t hi, uint32_t k)
+    // [lo,hi) becomes tiles first .. first+k-1 of near-equal population.  The two halves of a split touch disjoint
+    // ranges of `order` and of `tile_p0`, so the upper levels of the recursion run their left halves on threads of
+    // their own (`fan` = levels left to fan out).
+    void split(uint32_t lo, uint32_t hi, uint32_t k, uint32_t first, int fan)
     {
-        // [lo,hi) becomes k tiles of near-equal population
         if (k <= 1) {
             std::sort(order.begin() + lo, order.begin() + hi); // slot order inside a tile
-            tile_p0.push_back(hi);
+            tile_p0[first + 1] = hi;
             return;
         }
         float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
@@ -68,10 +86,31 @@ struct Splitter {
             return a < b || (a == b && p < q);
         };
         std::nth_element(order.begin() + lo, order.begin() + lo + nl, order.begin() + hi, cmp);
-        split(lo, lo + nl, kl);
-        split(lo + nl, hi, k - kl);
+        if (fan > 0 && hi - lo > 65536) {
+            std::thread left([=] { split(lo, lo + nl, kl, first, fan - 1); });
+            split(lo + nl, hi, k - kl, first + kl, fan - 1);
+            left.join();
+        } else {
+            split(lo, lo + nl, kl, first, 0);
+            split(lo + nl, hi, k - kl, first + kl, 0);
+        }
     }
 };
+
+// recursive coordinate bisection of P particles into ceil(P / target) tiles; fills order and tile_p0
+inline void bisect(const std::vector<float> &px, const std::vector<float> &py, std::vector<uint32_t> &order,
+                   std::vector<uint32_t> &tile_p0, uint32_t target)
+{
+    const uint32_t P = (uint32_t)px.size();
+    order.resize(P);
+    for (uint32_t i = 0; i < P; i++) order[i] = i;
+    const uint32_t k = P ? (P + target - 1) / target : 0;
+    tile_p0.assign((size_t)k + 1, 0);
+    if (P) {
+        Splitter sp{px, py, order, tile_p0, target};
+        sp.split(0, P, k, 0, 4);
+    }
+}
 
 } // namespace sbt
 
@@ -81,15 +120,7 @@ inline void sb_build_tiling(SbTiling &t, const std::vector<float> &px, const std
 {
     const uint32_t P = (uint32_t)px.size(), B = (uint32_t)beams.size();
     target = std::max(64u, std::min(target, 16384u));
-    t.order.resize(P);
-    for (uint32_t i = 0; i < P; i++) t.order[i] = i;
-    t.tile_p0.clear();
-    t.tile_p0.push_back(0);
-    if (P) {
-        uint32_t k = (P + target - 1) / target;
-        sbt::Splitter sp{px, py, t.order, t.tile_p0, target};
-        sp.split(0, P, k);
-    }
+    sbt::bisect(px, py, t.order, t.tile_p0, target);
     t.ntiles = (uint32_t)t.tile_p0.size() - 1;
     std::vector<uint32_t> internal_of_slot(P), tile_of(P);
     for (uint32_t i = 0; i < P; i++) internal_of_slot[t.order[i]] = i;

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("tiling") / "tiling_check")
-    p = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "softbody-webgpu_amd", "csrc"),
+    p = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "softbody-webgpu_amd", "csrc"),
                         os.path.join(ROOT, "tests", "tiling_check.cpp"), "-o", out], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     return out
