@@ -308,6 +308,13 @@ sb_status sb_create(const sb_options *opts, sb_engine **out)
     e->prm.bounds_size = opts->bounds_size;
     e->prm.particle_radius = opts->particle_radius;
     e->prm.time_step = 1.0f / (float)e->subticks; // engineWorker.ts:331
+    {
+        const float dt2 = e->prm.time_step * e->prm.time_step;
+        uint32_t bits;
+        memcpy(&bits, &dt2, 4);
+        const bool pow2 = (bits & 0x007fffffu) == 0u && (bits >> 23) > 1u && (bits >> 23) < 253u; // normal, exact reciprocal
+        e->prm.inv_dt2 = pow2 ? 1.0f / dt2 : 0.0f;
+    }
     // the all-pairs scan sums contacts in ascending slot order (compute.wgsl:144); only the
     // atomic path keeps particles in slot order, so it serves that mode
     e->path = opts->path != SB_PATH_AUTO ? opts->path

@@ -25,6 +25,9 @@ static_assert(sizeof(SbConsts) == 64, "metadata tail is 64 bytes");
 // pipeline-overridable constants (compute.wgsl:1-3, engineWorker.ts:328-332)
 struct SbParams {
     float bounds_size, particle_radius, time_step;
+    // time_step * time_step is a power of two whenever subticks is (the default 64 -> 2^-12): dividing by it (compute.wgsl:168)
+    // is then the exact multiplication by inv_dt2, bit for bit the IEEE quotient.  inv_dt2 = 0 means "divide".
+    float inv_dt2;
 };
 
 SB_DEV float sb_min(float a, float b) { return (b < a) ? b : a; }
@@ -302,17 +305,19 @@ struct SbParticle {
     float2 p, v, a;
 };
 
-// one iteration of the collision loop, compute.wgsl:148-169.  `self` is const_particle (:141).
-SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticity_coeff,
-                            SbParticle &particle, const SbParticle &self, uint32_t index,
-                            uint32_t other_index, float2 op, float2 ov)
+// one iteration of the collision loop, compute.wgsl:148-169.  `self` is const_particle (:141); (dx, dy) = other - self,
+// dist = length(dx, dy) as the caller already had to compute it for the contact test (:150).  The reciprocal of dist
+// takes the short exact form when every lane of the wave that is in contact has an ordinary distance (gate of
+// sb_rcp_gated; exhaustively checked, see above), x / 2 is x * 0.5 exactly, and x / dt^2 is a multiplication when dt^2
+// is a power of two.
+SB_DEV void sb_collide_pair_at(const SbParams &prm, float friction, float elasticity_coeff, SbParticle &particle,
+                               const SbParticle &self, uint32_t index, uint32_t other_index, float dx, float dy, float dist,
+                               float2 ov)
 {
-    float dx = op.x - self.p.x, dy = op.y - self.p.y;
-    float dist = sb_length(dx, dy); // :150
     if (dist == 0.0f) {             // :151-154
         particle.p.y += sb_sign((float)index - (float)other_index);
     } else if (dist < prm.particle_radius * 2.0f) { // :155
-        const float inv_dist = sb_div(1.0f, dist);
+        const float inv_dist = sb_wave_all(dist >= 0x1p-45f && dist <= 0x1p45f) ? sb_rcp_gated(dist) : sb_div(1.0f, dist);
         float nx = dx * inv_dist, ny = dy * inv_dist;         // :156
         float tx = -ny, ty = nx;                              // :157
         float ux = self.v.x - ov.x, uy = self.v.y - ov.y;     // :158
@@ -322,11 +327,23 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
         particle.v.x -= impulse_normal * nx + impulse_tangent * tx;   // :162
         particle.v.y -= impulse_normal * ny + impulse_tangent * ty;
         float overlap = prm.particle_radius * 2.0f - dist;            // :164
-        float csx = sb_div(nx * overlap, 2.0f), csy = sb_div(ny * overlap, 2.0f);
-        float dt2 = prm.time_step * prm.time_step;                    // :168
-        particle.a.x -= sb_div(csx, dt2);
-        particle.a.y -= sb_div(csy, dt2);
+        float csx = nx * overlap * 0.5f, csy = ny * overlap * 0.5f;   // (n * overlap) / 2
+        if (prm.inv_dt2 != 0.0f) {                                    // :168
+            particle.a.x -= csx * prm.inv_dt2;
+            particle.a.y -= csy * prm.inv_dt2;
+        } else {
+            float dt2 = prm.time_step * prm.time_step;
+            particle.a.x -= sb_div(csx, dt2);
+            particle.a.y -= sb_div(csy, dt2);
+        }
     }
+}
+SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticity_coeff,
+                            SbParticle &particle, const SbParticle &self, uint32_t index,
+                            uint32_t other_index, float2 op, float2 ov)
+{
+    float dx = op.x - self.p.x, dy = op.y - self.p.y;
+    sb_collide_pair_at(prm, friction, elasticity_coeff, particle, self, index, other_index, dx, dy, sb_length(dx, dy), ov);
 }
 
 // ---------------------------------------------------------------- spatial hash (SB_COLLIDE_GRID)
@@ -656,8 +673,9 @@ SB_DEV void sb_collide_list(const SbGrid &g, uint32_t count, const SbParams &prm
         const float ex = q.x - self.p.x, ey = q.y - self.p.y;
         const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
         if (d2 > far2) continue;            // sqrt is monotone: cannot give d < 2r, and is not 0
-        const float d = sb_sqrt(d2);
-        if (d == 0.0f || d < two_r) sb_collide_pair(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[id], q, vel_r[id]);
+        const float d = sb_wave_all(sb_in_sqrt_gate(d2)) ? sb_sqrt_gated(d2) : sb_sqrt(d2);
+        if (d == 0.0f || d < two_r)
+            sb_collide_pair_at(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[id], ex, ey, d, vel_r[id]);
     }
 }
 

@@ -550,3 +550,15 @@ def test_tiles_larger_than_the_prefetch_window(sb, oracle, tile, mode):
     assert info["tiles"] in (2, 3)
     assert_same(got, exp, "tile %d" % tile)
     assert (got.particles[:, 1] == 10.0).any()
+
+
+@pytest.mark.parametrize("subticks", [100, 36])
+def test_time_steps_that_are_not_powers_of_two(sb, oracle, subticks):
+    """dt^2 is a power of two for the default 64 subticks, and the contact response then multiplies by its exact
+    reciprocal instead of dividing (compute.wgsl:168); any other subtick count must take the IEEE division."""
+    buf = sb.scenes.default_buffers(1, 256, 512)
+    got, exp, _ = run_both(sb, oracle, buf, frames=2, mode=GRID, ref_mode=ALLPAIRS, subticks=subticks)
+    assert_same(got, exp, "subticks %d" % subticks)
+    pile, bounds = sb.scenes.blob_pile_buffers(6, 3, gap=19.7)
+    got, exp, _ = run_both(sb, oracle, pile, n=60, mode=GRID, ref_mode=GRID, bounds=bounds, subticks=subticks)
+    assert_same(got, exp, "pile, subticks %d" % subticks)

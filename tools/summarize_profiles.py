@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 if not os.path.isdir(src) or not glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
@@ -56,7 +56,16 @@ if os.path.exists(bg):
     shutil.copy(bg, os.path.join(dst, "%s_bench_grid.json" % tag))
     summary["bench_grid"] = json.loads(open(bg).read().strip().splitlines()[-1])
 
-for name, out in (("exchange_cost.txt", "%s_exchange_cost.txt"), ("rehearse_2ranks.json", "%s_rehearse_2ranks_one_gpu.json"),
+kc = one("trace_cfg3/*/*_kernel_stats.csv")
+if kc:
+    shutil.copy(kc, os.path.join(dst, "%s_config3_kernel_stats.csv" % tag))
+    summary["config3_kernel_stats"] = [{"name": r["Name"].split("(")[0], "calls": int(r["Calls"]),
+                                        "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
+                                       for r in csv.DictReader(open(kc))]
+for name, out in (("bench_config3.json", "%s_bench_config3.json"), ("bench_single_substep.json", "%s_bench_single_substep.json"),
+                  ("bench_4M.json", "%s_bench_4M.json"), ("bench_16M.json", "%s_bench_16M.json"),
+                  ("upload_timing.txt", "%s_upload_timing.txt"),
+                  ("exchange_cost.txt", "%s_exchange_cost.txt"), ("rehearse_2ranks.json", "%s_rehearse_2ranks_one_gpu.json"),
                   ("node_bench.json", "%s_node_bench.json"), ("cfg4_share.json", "%s_cfg4_share.json"),
                   ("cfg5_share.json", "%s_cfg5_share.json"),
                   ("bench_config3_contacts.json", "%s_bench_config3_lattice_on_floor.json"),
@@ -83,20 +92,26 @@ f_corr = sum(rd) / len(rd) if rd else 2.0
 w_corr = sum(wr) / len(wr) if wr else 1.0
 summary["fetch_correction"] = f_corr
 summary["write_correction"] = w_corr
-traffic = {}
-for which, ctr, corr in (("pmc_fetch", "FETCH_SIZE", f_corr), ("pmc_write", "WRITE_SIZE", w_corr)):
-    for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
-        if c == ctr and k.startswith("void k_"):
+def traffic_of(suffix):
+    traffic = {}
+    for which, ctr, corr in (("pmc_fetch" + suffix, "FETCH_SIZE", f_corr), ("pmc_write" + suffix, "WRITE_SIZE", w_corr)):
+        for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
             name = k.split("(")[0].replace("void ", "")
-            traffic.setdefault(name, {})[ctr] = {"launches": n, "counter_KiB": avg, "bytes": avg * 1024.0 * corr}
-for name, t in traffic.items():
-    t["hbm_bytes_per_launch"] = sum(x["bytes"] for x in t.values() if isinstance(x, dict))
+            if c == ctr and name.startswith("k_"):
+                traffic.setdefault(name, {})[ctr] = {"launches": n, "counter_KiB": avg, "bytes": avg * 1024.0 * corr}
+    for name, t in traffic.items():
+        t["hbm_bytes_per_launch"] = sum(x["bytes"] for x in t.values() if isinstance(x, dict))
+    return traffic
+
+
+traffic = traffic_of("")
 summary["traffic"] = traffic
+summary["traffic_config3"] = traffic_of("_cfg3")   # k_substep_tiled_grid and k_grid_maintain on the settled blob pile
 sq = {}
 for which in ("pmc_sq1", "pmc_sq2"):
     for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
-        if k.startswith("void k_substep_tiled"):
+        if "k_substep" in k:
             sq.setdefault(k.split("(")[0].replace("void ", ""), {})[c] = {"launches": n, "per_launch": avg}
 summary["sq_counters"] = sq
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("kernel_stats", "traffic", "fetch_correction", "write_correction") if k in summary}, indent=1))
+print(json.dumps({k: summary[k] for k in ("kernel_stats", "traffic", "traffic_config3", "fetch_correction", "write_correction") if k in summary}, indent=1))
