@@ -22,7 +22,7 @@ class WGPUSoftbodyEngineWorker {
     /**
      * @param canvas ignored (kept for signature compatibility; there is no render pass)
      * @param opts {particleRadius, subticks} as in the reference, plus {boundsSize, layout,
-     *        maxParticles, maxBeams, collisionMode, path, tileParticles, device, gridSkin}
+     *        maxParticles, maxBeams, collisionMode, path, tileParticles, device, gridSkin, blockSubsteps}
      * @param post function(message) receiving {type, data} replies
      */
     constructor(canvas, opts, post) {
@@ -42,7 +42,7 @@ class WGPUSoftbodyEngineWorker {
             maxParticles: this.bufferMapper.maxParticles, maxBeams: this.bufferMapper.maxBeams, layout: this.layout,
             collisionMode: o.collisionMode !== undefined ? o.collisionMode : COLLIDE.GRID, // same bits as ALLPAIRS
             path: o.path !== undefined ? o.path : PATH.AUTO, tileParticles: o.tileParticles || 0, device: o.device || 0,
-            gridSkin: o.gridSkin || 0
+            gridSkin: o.gridSkin || 0, blockSubsteps: o.blockSubsteps || 0
         });
         this.running = true;
         this.visible = true;

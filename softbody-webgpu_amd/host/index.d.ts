@@ -151,6 +151,7 @@ export type NativeEngineOptions = Partial<WGPUSoftbodyEngineOptions> & {
     readonly tileParticles?: number
     readonly device?: number
     readonly gridSkin?: number          // spatial-hash reuse margin; 0/undefined = adaptive (0.4 r .. 1.6 r), > 0 = fixed
+    readonly blockSubsteps?: number     // collisions off: substeps per launch (0/undefined = 5, 1 = one launch per substep)
 };
 
 export class WGPUSoftbodyEngine {
@@ -208,3 +209,35 @@ export function native(): Record<string, (...args: unknown[]) => unknown>;
 
 /** headless software renderer of render.wgsl's picture (debugging only): binary PPM (P6) */
 export function renderPPM(mapper: BufferMapper, opts?: { boundsSize?: number, particleRadius?: number, resolution?: number }): Buffer;
+
+/** multi-GPU sharding from the Node host (host/halo.js; C library sb_partition_*, sb_halo_*, sb_peer_*) */
+export type HaloPeer = { readonly rank: number, readonly ghostP: Uint32Array, readonly sendP: Uint32Array,
+    readonly ghostB: Uint32Array, readonly sendB: Uint32Array };
+export class HaloPlan {
+    readonly rank: number; readonly world: number; readonly depth: number;
+    readonly nLocal: number; readonly nOwned: number;
+    readonly ownedParticles: Uint32Array; readonly ownedBeams: Uint32Array;
+    readonly peers: HaloPeer[];
+    readonly globalParticleId: Uint32Array; readonly globalBeamKey: Uint32Array;
+    lists(): [Uint32Array, Uint32Array, Uint32Array, Uint32Array];
+    segments(): { segments: { rank: number, send: [number, number], recv: [number, number] }[], sendFloats: number,
+        recvFloats: number, offsets: [Uint32Array, Uint32Array, Uint32Array, Uint32Array] };
+}
+export type RankScene = { readonly rank: number, readonly layout: 1 | 2, readonly maxParticles: number, readonly maxBeams: number,
+    readonly metadata: ArrayBuffer, readonly mapping: ArrayBuffer, readonly particleData: ArrayBuffer, readonly beamData: ArrayBuffer,
+    readonly plan: HaloPlan };
+/** any scene (a BufferMapper after writeState(), or its four buffers) -> x-slabs with ghost zones `depth` beam hops deep */
+export function partitionScene(scene: BufferMapper | { layout: 1 | 2, maxParticles: number, maxBeams: number, metadata: ArrayBuffer,
+    mapping: ArrayBuffer, particleData: ArrayBuffer, beamData: ArrayBuffer }, world: number, depth: number, contactReach?: number,
+    ranks?: number[]): RankScene[];
+export type PeerCard = { readonly rank: number, readonly pid: number, readonly pointer: number, readonly handle: number[],
+    readonly recvFloats: number, readonly recv: [number, number, number][] };
+export class PeerExchanger {
+    constructor(handle: unknown, plan: HaloPlan, timeoutMs?: number);
+    readonly card: PeerCard;
+    readonly connected: boolean;
+    connect(cardsByRank: (PeerCard | undefined)[]): void;
+    exchange(): void;
+    step(nSubsteps: number): void;
+    verify(): void;
+}
