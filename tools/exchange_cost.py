@@ -15,8 +15,14 @@ sb = ge.load_package()
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 W, H = 1000, 1000
-BASE_US = 20.0   # ghost-free 1M-particle slab, us per substep (profiles/r01_bench.json)
-for depth in (8, 16, 24, 32):
+base = sb.scenes.lattice_buffers(W, H, d=30.0, origin=(1000.0, 1000.0), jitter=1.0, layout=2)
+eng = sb.Engine(bounds_size=100000.0, layout=2, max_particles=base.max_particles, max_beams=base.max_beams, collision_mode=0)
+eng.write_buffers(base)
+eng.step(64)
+BASE_US = eng.step_timed(500) * 1e3 / 500   # the same slab without ghost columns, us per substep
+eng.destroy()
+del base
+for depth in (10, 15, 25, 35):
     for transport in ("rccl", "peer"):
         buf, plan = sb.halo.slab_scene(sb, 1, 3, W, H, jitter=1.0, depth=depth)
         eng = sb.Engine(bounds_size=100000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=0)
@@ -67,7 +73,7 @@ for depth in (8, 16, 24, 32):
             e1.record()
         eng.sync(); torch.cuda.synchronize()
         loop_us = e0.elapsed_time(e1) * 1e3 / (periods * depth)
-        print("depth %2d %s: payload %.2f MB, exchange alone %.1f us; loop %.2f us/substep (stepping alone %.2f) = +%.1f%% over a ghost-free slab at %.1f us"
+        print("depth %2d %s: payload %.2f MB, exchange alone %.1f us; loop %.2f us/substep (stepping alone %.2f) = %+.1f%% over a ghost-free slab at %.2f us"
               % (depth, transport, n_send * 4 / 1e6, alone_us, loop_us, pure_us, 100 * (loop_us / BASE_US - 1), BASE_US), flush=True)
         eng.destroy()
 dist.destroy_process_group()
