@@ -227,11 +227,24 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(SB_BK_W
                     t_in[u] = tg[i];
                     l_in[u] = ls[i];
                 }
-                if (AUX && s == k_run) sb_beam_group<SB_BK_G, true>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
-                else sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
+                sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
 #pragma unroll
                 for (int u = 0; u < SB_BK_G; u++) {
                     const int i = i0 + u;
+                    if (AUX && s == k_run) {
+                        // strain/stress (compute.wgsl:122-123) are outputs of the last substep of a call, for owned beams
+                        // only: recomputed here from what is still in registers -- tg/ls hold the beam's state BEFORE this
+                        // substep, l_in its new length -- with the operations of sb_beam_eval in the same order, instead of
+                        // a second instantiation of the group in the loop (which spilled 300 bytes per thread)
+                        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+                        if (j < n_ownb && word[i] != bp.dummy_word) {
+                            const float len = l_in[u];
+                            const float force_mag = (tg[i] - len) * mt[u].spring + (ls[i] - len) * mt[u].damp; // :110
+                            const float strain_v = (len - tg[i]) * mt[u].inv_length;                           // :112
+                            bs.stress[b0 + j] = force_mag * (1.0f / 20.0f);                                    // :122
+                            bs.strain[b0 + j] = sb_div(sb_abs(strain_v), mt[u].yield_strain);                  // :123
+                        }
+                    }
                     tg[i] = t_in[u];
                     ls[i] = l_in[u];
                     if (__builtin_expect(broken[u], 0)) brk |= 1u << i;
@@ -239,13 +252,6 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(SB_BK_W
                     atomicAdd(&s_fy[la[u]], fa[u][1]);
                     atomicAdd(&s_fx[lb[u]], fb[u][0]);
                     atomicAdd(&s_fy[lb[u]], fb[u][1]);
-                    if (AUX && s == k_run) { // strain/stress: outputs of the last substep of a call (compute.wgsl:122-123)
-                        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
-                        if (j < n_ownb && word[i] != bp.dummy_word) {
-                            bs.strain[b0 + j] = strain[u];
-                            bs.stress[b0 + j] = stress[u];
-                        }
-                    }
                 }
             }
         }

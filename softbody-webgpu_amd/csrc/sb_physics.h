@@ -660,6 +660,9 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
 // The collision loop of compute.wgsl:144-170 over particle i's neighbour list (`count` = nl_count[i], fetched
 // by the caller ahead of time).  The list is slot-sorted and every test uses the frozen copy `self`, so
 // walking it and applying the contacts found is the ascending-slot order of the all-pairs scan.
+#ifndef SB_NL_BATCH
+#define SB_NL_BATCH 2
+#endif
 SB_DEV void sb_collide_list(const SbGrid &g, uint32_t count, const SbParams &prm, float friction,
                             float elasticity_coeff, SbParticle &particle, const SbParticle &self, uint32_t i,
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
@@ -667,15 +670,36 @@ SB_DEV void sb_collide_list(const SbGrid &g, uint32_t count, const SbParams &prm
 {
     const float two_r = prm.particle_radius * 2.0f;
     const float far2 = two_r * two_r * 1.001f;
-    for (uint32_t k = 0; k < count; k++) { // count is a real length here, never SB_NL_OVERFLOW
-        const uint32_t id = g.nl[k * g.nl_stride + i];
-        const float2 q = pos_r[id];
-        const float ex = q.x - self.p.x, ey = q.y - self.p.y;
-        const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
-        if (d2 > far2) continue;            // sqrt is monotone: cannot give d < 2r, and is not 0
-        const float d = sb_wave_all(sb_in_sqrt_gate(d2)) ? sb_sqrt_gated(d2) : sb_sqrt(d2);
-        if (d == 0.0f || d < two_r)
-            sb_collide_pair_at(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[id], ex, ey, d, vel_r[id]);
+    // Entries are taken SB_NL_BATCH at a time (2 measured best: 54.0 / 48.2 / 49.2 us per substep of the config-3 pile for 1 / 2 / 4):
+    // all their indices are requested together, then all their positions, then
+    // the velocities of those near enough to matter -- three dependent rounds of loads per batch instead of two per
+    // entry (a list of four used to cost eight dependent L2 latencies; the walk is latency-bound).  The contacts of
+    // a batch are still applied in list order, i.e. ascending slot order.
+    for (uint32_t k0 = 0; k0 < count; k0 += SB_NL_BATCH) { // count is a real length here, never SB_NL_OVERFLOW
+        uint32_t id[SB_NL_BATCH];
+        float2 q[SB_NL_BATCH], ov[SB_NL_BATCH];
+        float d2[SB_NL_BATCH];
+#pragma unroll
+        for (int j = 0; j < SB_NL_BATCH; j++) id[j] = k0 + (uint32_t)j < count ? g.nl[(k0 + (uint32_t)j) * g.nl_stride + i] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < SB_NL_BATCH; j++) q[j] = id[j] != 0xFFFFFFFFu ? pos_r[id[j]] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SB_NL_BATCH; j++) {
+            const float ex = q[j].x - self.p.x, ey = q[j].y - self.p.y;
+            d2[j] = ex * ex + ey * ey; // exactly the argument length() takes the root of
+            // sqrt is monotone: d2 clearly above (2r)^2 cannot give d < 2r, and is not 0
+            if (id[j] == 0xFFFFFFFFu || d2[j] > far2) id[j] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < SB_NL_BATCH; j++) ov[j] = id[j] != 0xFFFFFFFFu ? vel_r[id[j]] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SB_NL_BATCH; j++) {
+            if (id[j] == 0xFFFFFFFFu) continue;
+            const float ex = q[j].x - self.p.x, ey = q[j].y - self.p.y;
+            const float d = sb_wave_all(sb_in_sqrt_gate(d2[j])) ? sb_sqrt_gated(d2[j]) : sb_sqrt(d2[j]);
+            if (d == 0.0f || d < two_r)
+                sb_collide_pair_at(prm, friction, elasticity_coeff, particle, self, pidx[i], pidx[id[j]], ex, ey, d, ov[j]);
+        }
     }
 }
 

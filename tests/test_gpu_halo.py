@@ -240,3 +240,51 @@ def test_halo_and_peer_argument_checks(sb):
     e.sync()
     e.destroy()
 
+
+
+@pytest.mark.parametrize("world,mode", [(2, 2), (3, 0)])
+def test_partitioned_scene_on_engines_equals_single_engine(sb, world, mode):
+    """halo.partition_scene (C library sb_partition_*) on real engines wired by sb_peer_*: a pile of blobs in contact
+    cut into slabs (spatial-hash collisions, contact band + 2 beam hops of ghosts), and the reference's default scene cut
+    in three (beams only) -- the owned particles and beams of all ranks together equal the single-engine run bit for bit."""
+    halo = sb.halo
+    if mode == 2:
+        buf, bounds = sb.scenes.blob_pile_buffers(12, 4, gap=19.7)
+        depth, reach, steps = 2, 2 * (30.0 * 2 ** 0.5 + 22.0), 60
+    else:
+        buf, bounds = sb.scenes.default_buffers(2, 256, 512), 1000.0
+        depth, reach, steps = 3, 0.0, 96
+
+    def engine_for(b):
+        e = sb.Engine(bounds_size=bounds, layout=2, max_particles=b.max_particles, max_beams=b.max_beams, collision_mode=mode,
+                      tile_particles=256)
+        e.write_buffers(b)
+        return e
+
+    ref = engine_for(buf)
+    ref.step(steps)
+    want = ref.load_buffers(buf.copy())
+    ref.destroy()
+    made = [(lb, plan, engine_for(lb)) for lb, plan in halo.partition_scene(buf, world, depth, contact_reach=reach)]
+    assert all(0 < plan.n_owned < buf.particle_count for _, plan, _ in made)
+    exs = [halo.PeerExchanger(e, plan, timeout_ms=4000) for _, plan, e in made]
+    cards = [ex.card for ex in exs]
+    for ex in exs:
+        ex.connect(cards)
+    done = 0
+    while done < steps:
+        m = min(depth, steps - done)
+        for ex in exs:
+            ex.step(m)
+        done += m
+    seen = 0
+    for (lb, plan, e), ex in zip(made, exs):
+        ex.verify()
+        out = e.load_buffers(lb.copy())
+        e.destroy()
+        gid = plan.global_particle_id[plan.owned_particles]
+        assert np.array_equal(out.particles[plan.owned_particles].view("u4"), want.particles[gid].view("u4"))
+        for k, rec in zip(plan.global_beam_key[plan.owned_beams], out.beams[plan.owned_beams]):
+            assert rec.tobytes()[8:] == want.beams[int(k)].tobytes()[8:]
+        seen += gid.size
+    assert seen == buf.particle_count and not np.array_equal(want.particles, buf.particles)
