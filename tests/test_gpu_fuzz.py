@@ -87,3 +87,71 @@ def test_random_scene_grid_equals_allpairs(sb, oracle, seed):
         compared += 1
     eng.destroy()
     assert compared == chunks, "seed %d went non-finite after %d of %d checkpoints" % (seed, compared, chunks)
+
+
+def make_beam_case(sb, seed):
+    """Collisions off (the temporally blocked kernel's domain): several lattice blobs of different shapes and materials,
+    some joined by long beams (rings then grow across blobs), with yield and break limits in reach, random constants."""
+    rng = np.random.default_rng(5000 + seed)
+    bounds = float(rng.choice([1000.0, 1600.0, 3000.0]))
+    parts, beams, base, anchors = [], [], 0, []
+    for _ in range(int(rng.integers(2, 7))):
+        w, h = int(rng.integers(2, 24)), int(rng.integers(2, 24))
+        d = float(rng.uniform(12.0, 40.0))
+        ox, oy = rng.uniform(20, max(21.0, bounds - 20 - w * d)), rng.uniform(20, max(21.0, bounds - 20 - h * d))
+        p, b = sb.scenes.rectangle(ox, oy, d, w, h, float(rng.choice([1, 3, 50, 500])), float(rng.choice([10, 50, 700])),
+                                   float(rng.choice([0.02, 0.2, 2.0])), float(rng.choice([0.1, 0.5, 1e9])), base=base,
+                                   anti_diagonal=bool(rng.integers(0, 2)), layout=2)
+        pv = np.zeros((p.shape[0], 6), "f4")
+        pv[:, :2] = p + rng.uniform(-1.5, 1.5, p.shape).astype("f4")
+        pv[:, 2:4] = rng.uniform(-30, 30, 2).astype("f4")
+        parts.append(pv)
+        beams.append(b)
+        anchors.append((base, p.shape[0], pv))
+        base += p.shape[0]
+    extra = np.zeros(int(rng.integers(0, 6)), sb.layout.BEAM_DTYPE[2])   # long beams between blobs, arbitrary rest lengths
+    for k in range(extra.size):
+        (b0, n0, p0), (b1, n1, p1) = [anchors[i] for i in rng.choice(len(anchors), 2, replace=False)]
+        i, j = int(rng.integers(0, n0)), int(rng.integers(0, n1))
+        L = np.float32(np.hypot(*(p0[i, :2] - p1[j, :2])) * rng.uniform(0.8, 1.2))
+        extra[k] = (b0 + i, b1 + j, L, L, L, rng.choice([1.0, 3.0]), 50.0, 2.0, 1e9, 0.0, 0.0)
+    P = np.concatenate(parts)
+    B = np.concatenate(beams + [extra])
+    buf = sb.Buffers(2, P.shape[0] + 3, B.shape[0] + 9)
+    buf.set_scene(P, B)
+    drag_coeff, drag_exp = [(0.0, 2.0), (0.002, 2.0), (0.002, 2.5), (0.00002, 3.0), (0.02, 1.0)][int(rng.integers(0, 5))]
+    consts = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-1.0, 0.2), rng.uniform(0, 1), rng.uniform(0, 1),
+                       rng.uniform(0, 1), rng.uniform(0, 1), drag_coeff, drag_exp], "f4")
+    ui = buf.copy()
+    ui.user_strength = float(rng.uniform(0.5, 2.0))
+    ui.set_user_input(applied_force=tuple(rng.uniform(-0.3, 0.3, 2)), mouse_pos=tuple(rng.uniform(0, bounds, 2)),
+                      mouse_vel=tuple(rng.uniform(-5, 5, 2)), mouse_active=bool(rng.integers(0, 2)))
+    return buf, bounds, consts, ui.user_input_bytes(), int(rng.choice([64, 160, 512])), int(rng.integers(1, 9))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_beam_scene_blocked_equals_oracle(sb, oracle, seed):
+    """Seeded fuzzing of the temporally blocked kernel: random block depth (1-8), tile size, scene and constants, odd
+    substep counts with frames (delete passes) in between; bit for bit at every checkpoint, mapping included."""
+    buf, bounds, consts, ui, tile, K = make_beam_case(sb, seed)
+    eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                    collision_mode=OFF, path=2, tile_particles=tile, block_substeps=K)
+    ref = oracle.OracleEngine(bounds, 10.0, 64, 2, OFF, threads=8)
+    for e in (eng, ref):
+        e.write_buffers(buf)
+        e.write_user_input(ui)
+        e.set_physics_constants(consts)
+    for k in range(4):
+        n = 13 + 11 * k
+        eng.step(n)
+        ref.step(n)
+        if k % 2:
+            eng.frame()
+            ref.frame()
+        got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+        assert np.isfinite(exp.particles[:exp.particle_count]).all(), "seed %d is not a finite case" % seed
+        assert (got.particle_count, got.beam_count) == (exp.particle_count, exp.beam_count)
+        assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")), "seed %d chunk %d" % (seed, k)
+        assert got.beams.tobytes() == exp.beams.tobytes(), "seed %d chunk %d beams" % (seed, k)
+        assert np.array_equal(got.mapping, exp.mapping)
+    eng.destroy()
