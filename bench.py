@@ -153,7 +153,7 @@ def cpu_baseline_config3(sb, buf, bounds, budget_s):
                                          small.particle_count, ap["substeps"], ap["seconds"], cores)}
 
 
-def committed_traffic(workload, kernel):
+def committed_traffic(workload, kernel, key="bench"):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
     (profiles/rNN_summary.json, made by tools/gpu_profile.sh + tools/summarize_profiles.py from
     separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE x2 per the
@@ -165,8 +165,9 @@ def committed_traffic(workload, kernel):
             s = json.load(open(f))
             if s.get("bench", {}).get("config", {}).get("workload") != workload:
                 continue
+            table = s.get("traffic", {}) if key == "bench" else s.get("traffic_" + key, {})
             cand = [(max(v["launches"] for v in t.values() if isinstance(v, dict)), t["hbm_bytes_per_launch"])
-                    for name, t in s.get("traffic", {}).items() if name.startswith(kernel)]
+                    for name, t in table.items() if name.startswith(kernel + "<")]
             if cand:  # the variant launched most often (the lean substep; the last one of a call also stores strain/stress)
                 best = (max(cand)[1], os.path.basename(f))
         except Exception:
@@ -262,6 +263,30 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
         roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
         roof["traffic_over_compulsory"] = tr[0] / (own * k)
     return roof
+
+
+def measure_single_substep(sb, a, buf, bounds, workload):
+    """The same workload with ONE substep per launch (k_substep_tiled): the HBM-bound form of the
+    force-accumulate kernel, whose compulsory bytes the PMC counters reproduce; reported beside the blocked kernel
+    of the headline, which trades HBM traffic for redundant ring work and is not HBM-bound."""
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2, max_particles=buf.max_particles,
+                    max_beams=buf.max_beams, collision_mode=0, block_substeps=1)
+    eng.write_buffers(buf)
+    eng.step(a.warmup)
+    eng.sync()
+    ms = eng.step_timed(a.steps)
+    eng.sync()
+    own = float(eng.info("substep_hbm_bytes"))
+    per = ms * 1e-3 / a.steps
+    rec = {"kernel": eng.kernel_name(), "us_per_substep": per * 1e6, "value": buf.particle_count * a.steps / (ms * 1e-3),
+           "unit": "particle-steps/s", "compulsory_bytes_per_launch": own, "achieved_GBps": own / per / 1e9,
+           "frac_of_hbm_peak": own / per / 1e9 / HBM_PEAK_GBS}
+    tr = committed_traffic(workload, "k_substep_tiled", key="bench_single_substep")
+    if tr:
+        rec["traffic"] = tr[0]
+        rec["traffic_source"] = "profiles/%s" % tr[1]
+    eng.destroy()
+    return rec
 
 
 def measure_config3(sb, a):
@@ -470,6 +495,8 @@ def main():
         else:
             line["cpu_baseline"] = None
         if world == 1 and not a.no_extra and not (a.config3 or a.soup):
+            if mode == 0 and line["roofline"] and line["roofline"]["substeps_per_launch"] > 1:
+                line["extra"]["single_substep_kernel"] = measure_single_substep(sb, a, buf, bounds, workload)
             line["extra"]["config3"] = measure_config3(sb, a)
         print(json.dumps(line), flush=True)
     if dist is not None:

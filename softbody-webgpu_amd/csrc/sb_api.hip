@@ -467,7 +467,19 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     std::vector<uint32_t> order; // internal -> slot
     if (e->path == SB_PATH_TILED) {
         uint32_t target = e->opt.tile_particles ? e->opt.tile_particles : 1024;
-        if (e->opt.collision_mode == SB_COLLIDE_OFF && e->opt.block_substeps != 1 && P && B) {
+        const bool want_blocked = e->opt.collision_mode == SB_COLLIDE_OFF && e->opt.block_substeps != 1 && P && B;
+        if (want_blocked && !e->opt.tile_particles) {
+            // The blocked kernel keeps two tiles per CU resident (128 VGPRs), i.e. `slots` tiles at a time, and a launch
+            // runs in whole rounds of them: 1026 tiles on 512 slots take three rounds where 1024 take two (a slab with its
+            // ghost columns ran 27 % slower than the same slab without, for 5 % more particles).  So the tile size follows
+            // the scene: the fewest rounds whose tiles stay within ~1100 particles, and then tiles that fill those rounds.
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+            const uint64_t slots = (uint64_t)std::max(cus, 1) * 2u;
+            const uint64_t rounds = std::max<uint64_t>(1, (P + slots * 1100u - 1) / (slots * 1100u));
+            target = (uint32_t)std::min<uint64_t>(1100u, std::max<uint64_t>(256u, (P + slots * rounds - 1) / (slots * rounds)));
+        }
+        if (want_blocked) {
             // K substeps per launch, K as large as asked for while every tile's region still fits the kernel's
             // per-thread register arrays and 12-bit local indices
             const uint32_t region_cap = std::min<uint32_t>(SB_BK_MAXP * SB_BK_T, (1u << SB_BK_LBITS) - 2u);
@@ -479,6 +491,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         if (blockK) {
             order = bl.order;
         } else {
+            if (!e->opt.tile_particles) target = 1024; // the single-substep kernel's own default
             sb_build_tiling(tl, px, py, hb, target);
             order = tl.order;
         }

@@ -45,8 +45,11 @@ struct SbBlockedState {
 #define SB_BK_DUMMY_B (SB_BK_CAP - 1u)
 #define SB_BK_ROW 8u // LDS material row: length, 1/length, spring, damp, yield, yield*length, length*limit, limit
 
+#ifndef SB_BK_WAVES_AUX
+#define SB_BK_WAVES_AUX SB_BK_WAVES
+#endif
 template <int MAT, bool AUX>
-__global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(SB_BK_WAVES, SB_BK_WAVES))) void k_substep_blocked(
+__global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
     const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, uint32_t dephase_lo, uint32_t dephase_hi, uint32_t dephase_ticks)
 {
@@ -227,24 +230,29 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(SB_BK_W
                     t_in[u] = tg[i];
                     l_in[u] = ls[i];
                 }
-                sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
+                if (AUX && s == k_run) {
+                    // strain/stress (compute.wgsl:122-123) are outputs of the last substep of a call, for owned beams only:
+                    // a small evaluation of its own BEFORE the group -- the beam's length once more, then the operations of
+                    // sb_beam_eval in the same order -- whose registers are free again when the group starts (computed inside
+                    // or after the group they cost the strain/stress variant 270-300 bytes of scratch per thread)
 #pragma unroll
-                for (int u = 0; u < SB_BK_G; u++) {
-                    const int i = i0 + u;
-                    if (AUX && s == k_run) {
-                        // strain/stress (compute.wgsl:122-123) are outputs of the last substep of a call, for owned beams
-                        // only: recomputed here from what is still in registers -- tg/ls hold the beam's state BEFORE this
-                        // substep, l_in its new length -- with the operations of sb_beam_eval in the same order, instead of
-                        // a second instantiation of the group in the loop (which spilled 300 bytes per thread)
-                        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+                    for (int u = 0; u < SB_BK_G; u++) {
+                        const int i = i0 + u;
+                        uint32_t j = tid + (uint32_t)i * SB_BK_T;
+                        asm volatile("" : "+v"(j)); // (or the 24 store addresses of a thread are hoisted out of the substep loop: 48 VGPRs)
                         if (j < n_ownb && word[i] != bp.dummy_word) {
-                            const float len = l_in[u];
+                            const float len = sb_beam_length(qa[u], qb[u]);
                             const float force_mag = (tg[i] - len) * mt[u].spring + (ls[i] - len) * mt[u].damp; // :110
                             const float strain_v = (len - tg[i]) * mt[u].inv_length;                           // :112
                             bs.stress[b0 + j] = force_mag * (1.0f / 20.0f);                                    // :122
                             bs.strain[b0 + j] = sb_div(sb_abs(strain_v), mt[u].yield_strain);                  // :123
                         }
                     }
+                }
+                sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
+#pragma unroll
+                for (int u = 0; u < SB_BK_G; u++) {
+                    const int i = i0 + u;
                     tg[i] = t_in[u];
                     ls[i] = l_in[u];
                     if (__builtin_expect(broken[u], 0)) brk |= 1u << i;

@@ -234,6 +234,17 @@ SB_DEV SbBeamResult sb_beam_eval(float2 pa, float2 pb, float length, float inv_l
     return r;
 }
 
+// length of a beam exactly as sb_beam_eval / sb_beam_group compute it (:103-108): whichever branch is taken returns the
+// same bits on the gate's domain, so a caller may take its own
+SB_DEV float sb_beam_length(float2 pa, float2 pb)
+{
+    const float dx = pb.x - pa.x, dy = pb.y - pa.y;
+    const float len2 = dx * dx + dy * dy;
+    if (sb_wave_all(sb_in_sqrt_gate(len2))) return sb_sqrt_gated(len2);
+    const float len0 = sb_sqrt(len2);
+    return len0 == 0.0f ? sb_length(0.0f, -1.0e-10f) : len0; // the guard of :104-107
+}
+
 // G beams side by side, for the temporally blocked kernel (sb_blocked.hip): the same arithmetic as sb_beam_eval in
 // the same order, written stage by stage over the group so that the G dependency chains interleave in one
 // instruction stream and ONE wave-uniform gate decides between the short exact sqrt/reciprocal and the IEEE

@@ -81,13 +81,17 @@ def test_lattice_parity_1000_substeps(sb, oracle, path, tile):
 
 
 def test_lattice_64k_tiled(sb, oracle):
-    """256x256 = 65 536 particles / 195 585 beams, 64 tiles, falling onto the floor (border
-    response active), 128 substeps."""
+    """256x256 = 65 536 particles / 195 585 beams, 64 tiles of 1024, falling onto the floor (border
+    response active), 128 substeps; then the same with the tile size the engine picks for itself (256 tiles of
+    256: a scene this small fills the card's resident slots with smaller tiles)."""
     buf = sb.scenes.lattice_buffers(256, 256, d=30.0, origin=(40.0, 12.0), jitter=1.0, layout=2,
                                     velocity=(0.5, -3.0))
-    got, exp, info = run_both(sb, oracle, buf, n=128, mode=OFF, path=TILED, bounds=8000.0)
+    got, exp, info = run_both(sb, oracle, buf, n=128, mode=OFF, path=TILED, bounds=8000.0, tile=1024)
     assert info["tiles"] == 64
     assert_same(got, exp, "64k lattice")
+    got, exp, info = run_both(sb, oracle, buf, n=128, mode=OFF, path=TILED, bounds=8000.0)
+    assert info["tiles"] == 256
+    assert_same(got, exp, "64k lattice, automatic tile size")
     assert (got.particles[:, 1] == 10.0).any()  # some particles sit on the floor clamp
 
 

@@ -27,6 +27,10 @@ prof calib_write --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal
 # where the dominant kernel's time goes: SQ counters, two passes of eight
 prof pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- $BENCH
 prof pmc_sq2 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $BENCH
+# the same workload with one substep per launch (the HBM-bound kernel of DESIGN.md 4.2): traffic
+K1="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra --block-substeps 1"
+prof pmc_fetch_k1 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_k1 -- $K1
+prof pmc_write_k1 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_k1 -- $K1
 # config 3 (the settled blob pile, spatial-hash collisions): kernel trace and HBM traffic of its two kernels
 prof trace_cfg3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -- $CFG3
 prof pmc_fetch_cfg3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_cfg3 -- $CFG3

@@ -106,6 +106,7 @@ def traffic_of(suffix):
 
 traffic = traffic_of("")
 summary["traffic"] = traffic
+summary["traffic_bench_single_substep"] = traffic_of("_k1")   # k_substep_tiled, --block-substeps 1
 summary["traffic_config3"] = traffic_of("_cfg3")   # k_substep_tiled_grid and k_grid_maintain on the settled blob pile
 sq = {}
 for which in ("pmc_sq1", "pmc_sq2"):
