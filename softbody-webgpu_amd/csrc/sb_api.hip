@@ -1069,6 +1069,11 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             *value = n;
         }
     }
+    else if (k.rfind("grid_stamp_", 0) == 0) { // phase stamps of block 0 in the last hash build, 10 ns ticks since its start (diagnostic)
+        const int i = atoi(key + 11);
+        SB_HIP(e, hipStreamSynchronize(e->stream));
+        *value = (i >= 0 && i < 7 && e->dev_err) ? e->dev_err[4 + i] : 0;
+    }
     else if (k == "material_mode") *value = e->mat_mode;
     else if (k == "materials") *value = e->nmat;
     else if (k == "local_index_bits") *value = e->lbits;

@@ -539,6 +539,11 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         SB_AGENT_STORE(&cout->Cy, rebuild ? 0.0f : C_in_y + c_used_y);
     }
     if (!rebuild) return;
+#define SB_GRID_STAMP(k)                                                                                        \
+    do {                                                                                                        \
+        if (blockIdx.x == 0 && tid == 0) w.err[4 + (k)] = (uint32_t)(wall_clock64() - t_start); /* 10 ns ticks */ \
+    } while (0)
+    const uint64_t t_start = wall_clock64();
 
     const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
     // the cells of THIS hash (a wide skin means far fewer than the arrays were sized for; every count beyond them is
@@ -580,7 +585,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
     if (n_out && (tid & 63u) == 0u) atomicAdd(w.outside, n_out); // one per wave, and only when somebody left the frame
+    SB_GRID_STAMP(0);
     sb_grid_barrier(w.bar, bar0 + gridDim.x, w.err);
+    SB_GRID_STAMP(1);
     // every workgroup's count is in: ONE thread reads the total, publishes the verdict for the next build and re-zeroes the
     // counter (nobody touches it again before the count phase of the next build, a later launch)
     if (blockIdx.x == 0 && tid == 0) {
@@ -591,16 +598,17 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     // ---- exclusive scan of each 8192-cell chunk (1024 threads x 8 cells) + the chunk totals; clears the counts
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t base = chunk * SB_MT_CHUNK + tid * 8u;
-        uint32_t v[8], sum = 0;
+        uint32_t v[8], x[8], sum = 0;
+        // all eight counts are requested before any of them is re-zeroed: a store to the address a load is still in flight
+        // on waits for it, and eight such round trips in a row made this phase 49 of a rebuild's 89 us (r02, block 0's
+        // phase stamps: tools/grid_phases.py)
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = base + k < ncell1 ? SB_AGENT_LOAD(&w.cell_cnt[base + k]) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            uint32_t x = 0u;
-            if (base + k < ncell1) {
-                x = SB_AGENT_LOAD(&w.cell_cnt[base + k]);
-                w.cell_cnt[base + k] = 0u; // ready for the next build
-            }
+            if (base + k < ncell1) w.cell_cnt[base + k] = 0u; // ready for the next build
             v[k] = sum;
-            sum += x;
+            sum += x[k];
         }
         uint32_t inc = sum; // inclusive scan of the per-thread sums across the wave, then across the 16 waves
 #pragma unroll
@@ -619,7 +627,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         if (tid == SB_MT - 1) w.block_off[chunk] = excl + sum;
         __syncthreads();
     }
+    SB_GRID_STAMP(2);
     sb_grid_barrier(w.bar, bar0 + 2u * gridDim.x, w.err);
+    SB_GRID_STAMP(3);
     // ---- exclusive scan of the chunk totals: one workgroup walking 1024 at a time with a carry
     if (blockIdx.x == 0) {
         if (tid == 0) s_carry = 0;
@@ -642,7 +652,9 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             __syncthreads();
         }
     }
+    SB_GRID_STAMP(4);
     sb_grid_barrier(w.bar, bar0 + 3u * gridDim.x, w.err);
+    SB_GRID_STAMP(5);
     // ---- particles -> records sorted by cell, and the absolute first-record index of every cell
     for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
         uint32_t c[4], at[4], slot[4];
@@ -665,6 +677,8 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         }
     }
     for (uint32_t c = gtid; c < ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
+    SB_GRID_STAMP(6);
+#undef SB_GRID_STAMP
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
