@@ -704,12 +704,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.bounds = S;
         e->grid.wide_side = std::max(1u, (uint32_t)std::floor(std::sqrt((double)e->ncell)));
         const size_t n1 = (size_t)e->ncell + 1;
-        SB_TRY(dev_alloc(e, &e->d_cell_cnt, n1));
-        SB_HIP(e, hipMemset(e->d_cell_cnt, 0, n1 * 4));
-        SB_TRY(dev_alloc(e, &e->d_cell_scan, n1));
-        SB_TRY(dev_alloc(e, &e->d_cell_start, n1));
-        SB_TRY(dev_alloc(e, &e->d_block_off, (n1 + SB_SCAN_BLOCK - 1) / SB_SCAN_BLOCK));
-        SB_TRY(dev_alloc(e, &e->d_rank, P));
+        SB_TRY(dev_alloc(e, &e->d_head, n1));
+        SB_HIP(e, hipMemset(e->d_head, 0, n1 * 8)); // build number 0: "never written" (the first build is number 1)
         SB_TRY(dev_alloc(e, &e->d_rec, P));
         SB_TRY(dev_alloc(e, &e->d_cell_of, P));
         SB_TRY(dev_alloc(e, &e->d_grid_ctl, 2));
@@ -718,8 +714,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             SB_TRY(dev_alloc(e, &e->d_blk_max[k], 3 * nblk)); // max | sum dx | sum dy per workgroup
             SB_HIP(e, hipMemset(e->d_blk_max[k], 0, 3 * nblk * 4));
         }
-        SB_TRY(dev_alloc(e, &e->d_grid_bar, 1));
-        SB_HIP(e, hipMemset(e->d_grid_bar, 0, 4));
+        SB_TRY(dev_alloc(e, &e->d_grid_done, 1));
+        SB_HIP(e, hipMemset(e->d_grid_done, 0, 4));
         SB_TRY(dev_alloc(e, &e->d_grid_outside, 2));
         SB_HIP(e, hipMemset(e->d_grid_outside, 0, 8));
         SbGridCtl ctl[2] = {};
@@ -740,7 +736,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         }
         SB_HIP(e, hipMemcpy(e->d_grid_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
         e->grid_par = 0;
-        e->grid.cell_start = e->d_cell_start;
+        e->grid.head = e->d_head;
         e->grid.rec = e->d_rec;
         e->grid.cell_of = e->d_cell_of;
         SB_TRY(dev_alloc(e, &e->d_nl_count, P));
@@ -843,7 +839,6 @@ sb_status sb_sync(sb_engine *e)
     if (e->dev_err && *e->dev_err) {
         const uint32_t what = *e->dev_err;
         *e->dev_err = 0;
-        if (what & 0x80000000u) SB_FAIL(e, SB_ERR_HIP, "spatial hash build: device-wide barrier timed out (GPU oversubscribed?)");
         SB_FAIL(e, SB_ERR_HIP, "peer exchange: neighbour(s) 0x%x did not signal within %u ms", what, e->peer_timeout_ms);
     }
     return SB_OK;

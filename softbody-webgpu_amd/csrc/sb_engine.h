@@ -123,18 +123,14 @@ struct sb_engine {
     // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state when the displacement bound demands it
     SbGrid grid{};
     uint32_t ncell = 0;               // nx*ny (+1 spare entry in the per-cell arrays)
-    uint32_t *d_cell_cnt = nullptr;   // per cell: arrival counter (zero between builds)
-    uint32_t *d_cell_scan = nullptr;  // per cell: exclusive scan inside its 2048-cell block
-    uint32_t *d_block_off = nullptr;  // per 2048-cell block
-    uint32_t *d_cell_start = nullptr; // per cell: absolute first record
-    uint32_t *d_rank = nullptr;       // per particle: arrival rank inside its cell
+    unsigned long long *d_head = nullptr; // per cell: (build number << 32) | first record of its list (SbGrid::head)
     uint32_t *d_cell_of = nullptr;    // per particle: cell at the last build
-    float4 *d_rec = nullptr;          // records sorted by cell
+    float4 *d_rec = nullptr;          // per particle: {x, y at the build, slot, next record of its cell's list}
     SbGridCtl *d_grid_ctl = nullptr;  // [2] rebuild decision state by substep parity (device resident: no host sync per substep)
     uint32_t *d_blk_max[2] = {};      // per workgroup of the particle kernel: largest displacement (float bits), by parity
     uint32_t *d_nl_count = nullptr, *d_nl = nullptr; // neighbour lists (SbGrid)
     uint32_t *d_grid_outside = nullptr; // particles the hash build in progress found outside its frame (zero between builds)
-    uint32_t *d_grid_bar = nullptr;   // arrival counter of k_grid_maintain's device-wide barrier
+    uint32_t *d_grid_done = nullptr;  // workgroups of the hash build in progress that have finished (zero between builds)
     uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
     uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)
 

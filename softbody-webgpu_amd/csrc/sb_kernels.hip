@@ -407,46 +407,23 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 // ONE launch per substep (k_grid_maintain) in front of the particle kernel.  Every workgroup reduces the
 // previous substep's per-workgroup displacement maxima and takes the same decision (SbGridCtl,
 // sb_physics.h); on most substeps that is all and the kernel retires.  When the hash must be rebuilt the
-// SAME launch does it, as a persistent grid with device-wide barriers between the phases: count ->
-// block scan -> scan of the block sums -> scatter + absolute cell starts.  (Five separate launches that
-// each returned at once on 39 substeps out of 40 cost ~12 us per substep in launch boundaries alone.)
+// SAME launch does it in ONE pass with no device-wide barrier: every particle pushes itself on the front of its
+// cell's linked list with one 64-bit exchange (the head word carries the number of the build that wrote it, so the
+// cells of older builds read as empty and nothing is ever cleared), and writes its own record.  (Round 1 counted,
+// scanned and scattered into cell-sorted records: three device-wide barriers, a scan over every cell and two passes
+// over the particles, 70-90 us per build; tools/grid_phases.py.)
 // Decision state and the displacement slots are double buffered by substep parity: this launch reads
 // ctl[par] / blk_max[par] and publishes ctl[par^1]; the particle kernel that follows fills blk_max[par^1].
-
-// Device-wide barrier for a grid whose workgroups are all resident (<= SB_MAINTAIN_BLOCKS of 1024 threads, at most one per
-// CU, launched when the previous kernel of the stream has retired).  Monotone arrival counter; agent-scope
-// release before arriving and acquire after leaving make every workgroup's earlier writes visible to all
-// (the per-XCD L2s are not coherent for plain accesses).  The wait is bounded: on expiry the error word is
-// set and the workgroup moves on (a wrong hash and an error at the next sb_sync, never a hung wave).
-#define SB_MAINTAIN_BLOCKS 128u
-#define SB_MT 1024u               // threads per workgroup of k_grid_maintain: few fat workgroups, because every
-#define SB_MT_CHUNK (SB_MT * 8u)  // barrier arrival is an L2 write-back and its cost grows with the workgroup count
-#define SB_ERR_GRID_BARRIER 0x80000000u
-SB_DEV void sb_grid_barrier(uint32_t *bar, uint32_t target, uint32_t *err)
-{
-    // every wave first drains its own stores into L2 (the workgroup barrier alone does not wait for them on
-    // this target); thread 0's release then writes the L2 back before it arrives
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t t0 = wall_clock64();
-        while ((int32_t)(__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (wall_clock64() - t0 > 200000000ull) { // 2 s at 100 MHz
-                __hip_atomic_fetch_or(err, SB_ERR_GRID_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(24); // ~0.7 us between polls: hundreds of pollers on one address slow the arrivals down
-        }
-    }
-    __syncthreads();
-}
+#define SB_MAINTAIN_BLOCKS 64u // (measured on the 1 M pile: 64 -> 41.5, 128 -> 42.2, 256..1024 -> 44.7-45.0 us per substep;
+                              // the launch runs on every substep and only rebuilds on one in 4-14)
+#define SB_MT 1024u // threads per workgroup of k_grid_maintain
 
 struct SbGridBuild {
-    uint32_t *cell_cnt, *cell_scan, *block_off, *rank, *cell_of, *cell_start;
+    unsigned long long *head;
+    uint32_t *cell_of;
     float4 *rec;
-    uint32_t ncell1_cap;
-    uint32_t *bar, *err;
+    uint32_t *done;    // workgroups of the build in progress that have finished (zero between builds)
+    uint32_t *err;     // (words 4.. : block 0's phase stamps, tools/grid_phases.py)
     uint32_t *outside; // particles the build in progress found outside its frame (zero between builds)
 };
 
@@ -456,8 +433,6 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
                                                             SbGridBuild w)
 {
     __shared__ float s_wave_max[SB_MT / 64], s_wave_sx[SB_MT / 64], s_wave_sy[SB_MT / 64];
-    __shared__ uint32_t s_wave[SB_MT / 64];
-    __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x;
     // ---- decision, identical in every workgroup (everything read here was written by earlier launches)
     const SbGridCtl *cin = ctl + par;
@@ -546,21 +521,20 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     const uint64_t t_start = wall_clock64();
 
     const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
-    // the cells of THIS hash (a wide skin means far fewer than the arrays were sized for; every count beyond them is
-    // zero, because each build re-zeroes exactly the cells it counted into)
-    const uint32_t ncell1 = min(geo.nx * geo.ny + 1u, w.ncell1_cap), nchunks = (ncell1 + SB_MT_CHUNK - 1u) / SB_MT_CHUNK;
-    const uint32_t bar0 = builds * 3u * gridDim.x; // arrivals before this build (three barriers per build)
-    // ---- counts per cell, each particle's cell, and its arrival rank inside the cell (one returning atomic
-    // per particle; the arrival order is arbitrary, which is fine: contacts are re-ordered by slot)
+    const unsigned long long gen = (unsigned long long)(builds + 1u) << 32; // what the particle kernel reads as SbGridGeom::gen
+    // ---- every particle: its cell, itself pushed on the front of that cell's list (one returning exchange; the order
+    // inside a list is arbitrary, which is fine: contacts are re-ordered by slot), its record
     // (four particles per thread and round, so that four returning atomics are in flight per lane)
     uint32_t n_out = 0u;
     for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
-        uint32_t c[4], rk[4];
+        uint32_t c[4], slot[4];
+        unsigned long long old[4];
         float2 p[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = i0 + (uint32_t)u * nthreads;
             p[u] = i < P ? pos[i] : make_float2(0.f, 0.f);
+            slot[u] = i < P ? pslot[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -571,113 +545,44 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
             n_out += (have && o) ? 1u : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i0 + (uint32_t)u * nthreads < P) rk[u] = atomicAdd(&w.cell_cnt[c[u]], 1u);
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthreads;
+            if (i < P) old[u] = atomicExch(&w.head[c[u]], gen | i);
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = i0 + (uint32_t)u * nthreads;
             if (i < P) {
+                const uint32_t next = (old[u] >> 32) == (gen >> 32) ? (uint32_t)old[u] : SB_CHAIN_END;
                 w.cell_of[i] = c[u];
-                w.rank[i] = rk[u];
+                w.rec[i] = make_float4(p[u].x, p[u].y, __uint_as_float(slot[u]), __uint_as_float(next));
             }
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
-    if (n_out && (tid & 63u) == 0u) atomicAdd(w.outside, n_out); // one per wave, and only when somebody left the frame
+    // one per wave, and only when somebody left the frame; the RETURNING form: the wave has the old value back only once the
+    // add has been performed at the device's coherence point, which orders it before the workgroup's ticket below
+    if (n_out && (tid & 63u) == 0u) {
+        uint32_t seen = __hip_atomic_fetch_add(w.outside, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(seen));
+    }
     SB_GRID_STAMP(0);
-    sb_grid_barrier(w.bar, bar0 + gridDim.x, w.err);
+    // ---- the workgroup that finishes last reads the total, publishes the verdict for the next build and re-zeroes both
+    // counters (nobody touches them again before the next build, a later launch).  The ticket is a relaxed agent-scope
+    // read-modify-write: the counts it must follow are agent-scope atomics that have already returned, and everything else
+    // this kernel writes is read by LATER launches only.  (A release here writes the whole L2 back: ~10 us per build.)
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(w.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1u) {
+            const uint32_t total = __hip_atomic_load(w.outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            SB_AGENT_STORE(&ctl[par ^ 1u].wide_next, (wide != 0u || total > P / 64u) ? 1u : 0u);
+            SB_AGENT_STORE(w.outside, 0u);
+            SB_AGENT_STORE(w.done, 0u);
+        }
+    }
     SB_GRID_STAMP(1);
-    // every workgroup's count is in: ONE thread reads the total, publishes the verdict for the next build and re-zeroes the
-    // counter (nobody touches it again before the count phase of the next build, a later launch)
-    if (blockIdx.x == 0 && tid == 0) {
-        const uint32_t total = __hip_atomic_load(w.outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        SB_AGENT_STORE(&ctl[par ^ 1u].wide_next, (wide != 0u || total > P / 64u) ? 1u : 0u);
-        SB_AGENT_STORE(w.outside, 0u);
-    }
-    // ---- exclusive scan of each 8192-cell chunk (1024 threads x 8 cells) + the chunk totals; clears the counts
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint32_t base = chunk * SB_MT_CHUNK + tid * 8u;
-        uint32_t v[8], x[8], sum = 0;
-        // all eight counts are requested before any of them is re-zeroed: a store to the address a load is still in flight
-        // on waits for it, and eight such round trips in a row made this phase 49 of a rebuild's 89 us (r02, block 0's
-        // phase stamps: tools/grid_phases.py)
-#pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = base + k < ncell1 ? SB_AGENT_LOAD(&w.cell_cnt[base + k]) : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (base + k < ncell1) w.cell_cnt[base + k] = 0u; // ready for the next build
-            v[k] = sum;
-            sum += x[k];
-        }
-        uint32_t inc = sum; // inclusive scan of the per-thread sums across the wave, then across the 16 waves
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(inc, off, 64);
-            if ((tid & 63u) >= (uint32_t)off) inc += t;
-        }
-        if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (uint32_t k = 0; k < (tid >> 6); k++) wave_off += s_wave[k];
-        const uint32_t excl = wave_off + inc - sum;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (base + k < ncell1) w.cell_scan[base + k] = v[k] + excl;
-        if (tid == SB_MT - 1) w.block_off[chunk] = excl + sum;
-        __syncthreads();
-    }
-    SB_GRID_STAMP(2);
-    sb_grid_barrier(w.bar, bar0 + 2u * gridDim.x, w.err);
-    SB_GRID_STAMP(3);
-    // ---- exclusive scan of the chunk totals: one workgroup walking 1024 at a time with a carry
-    if (blockIdx.x == 0) {
-        if (tid == 0) s_carry = 0;
-        __syncthreads();
-        for (uint32_t base = 0; base < nchunks; base += SB_MT) {
-            const uint32_t x = base + tid < nchunks ? w.block_off[base + tid] : 0u;
-            uint32_t inc = x;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t t = __shfl_up(inc, off, 64);
-                if ((tid & 63u) >= (uint32_t)off) inc += t;
-            }
-            if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
-            __syncthreads();
-            uint32_t wave_off = s_carry;
-            for (uint32_t k = 0; k < (tid >> 6); k++) wave_off += s_wave[k];
-            if (base + tid < nchunks) w.block_off[base + tid] = wave_off + inc - x;
-            __syncthreads();
-            if (tid == SB_MT - 1) s_carry = wave_off + inc;
-            __syncthreads();
-        }
-    }
-    SB_GRID_STAMP(4);
-    sb_grid_barrier(w.bar, bar0 + 3u * gridDim.x, w.err);
-    SB_GRID_STAMP(5);
-    // ---- particles -> records sorted by cell, and the absolute first-record index of every cell
-    for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
-        uint32_t c[4], at[4], slot[4];
-        float2 p[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)u * nthreads;
-            const bool in = i < P;
-            c[u] = in ? w.cell_of[i] : 0u;
-            p[u] = in ? pos[i] : make_float2(0.f, 0.f);
-            at[u] = in ? w.rank[i] : 0u;
-            slot[u] = in ? pslot[i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) at[u] += w.cell_scan[c[u]] + w.block_off[c[u] / SB_MT_CHUNK];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)u * nthreads;
-            if (i < P) w.rec[at[u]] = make_float4(p[u].x, p[u].y, __uint_as_float(slot[u]), __uint_as_float(i));
-        }
-    }
-    for (uint32_t c = gtid; c < ncell1; c += nthreads) w.cell_start[c] = w.cell_scan[c] + w.block_off[c / SB_MT_CHUNK];
-    SB_GRID_STAMP(6);
 #undef SB_GRID_STAMP
 }
 
@@ -830,17 +735,14 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     const uint32_t mode = e->opt.collision_mode;
     if (mode == SB_COLLIDE_GRID && e->P) {
         // decide, and when the displacement bound demands it rebuild the spatial hash from the READ state
-        const uint32_t n = e->ncell + 1, nchunks = cdiv(n, SB_MT_CHUNK);
         const uint32_t nblk = e->path == SB_PATH_TILED ? e->ntiles : cdiv(e->P, SB_BLOCK);
-        const uint32_t work = std::max(cdiv(e->P, SB_MT), nchunks);
-        static const uint32_t max_blocks = [] { // tuning knob; every workgroup must be resident at once (see sb_grid_barrier)
+        static const uint32_t max_blocks = [] { // tuning knob (no residency requirement: the build has no device-wide barrier)
             const char *v = getenv("SB_MAINTAIN_BLOCKS");
             const long n = v ? atol(v) : 0;
-            return n >= 1 && n <= 2048 ? (uint32_t)n : SB_MAINTAIN_BLOCKS;
+            return n >= 1 && n <= 4096 ? (uint32_t)n : SB_MAINTAIN_BLOCKS;
         }();
-        const uint32_t blocks = std::min(std::max(work, 1u), max_blocks);
-        SbGridBuild gb{e->d_cell_cnt, e->d_cell_scan, e->d_block_off, e->d_rank, e->d_cell_of, e->d_cell_start,
-                       e->d_rec, n, e->d_grid_bar, e->dev_err, e->d_grid_outside};
+        const uint32_t blocks = std::min(std::max(cdiv(e->P, SB_MT * 4u), 1u), max_blocks);
+        SbGridBuild gb{e->d_head, e->d_cell_of, e->d_rec, e->d_grid_done, e->dev_err, e->d_grid_outside};
         k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
                                                             r.pos, e->d_pslot, e->P, e->grid, gb);
         e->grid_par ^= 1u;

@@ -366,8 +366,9 @@ SB_DEV void sb_collide_pair(const SbParams &prm, float friction, float elasticit
 // SUPERSET of the interacting pairs of compute.wgsl:144-170 wherever the particles are (clamping
 // only piles far-away particles into edge cells: slower, never wrong).
 struct SbGrid {
-    const uint32_t *cell_start; // per cell (+1 spare entry): absolute index of its first record
-    const float4 *rec;          // sorted by cell: {x, y AT BUILD TIME, bits(slot), bits(internal index)}
+    const unsigned long long *head; // per cell: (number of the build that wrote it) << 32 | first record of its chain; a stale
+                                    // build number reads as "empty", so no cell is ever cleared
+    const float4 *rec;          // per particle (record index == internal index): {x, y AT BUILD TIME, bits(slot), bits(next record)}
     const uint32_t *cell_of;    // per particle: its cell at the last build
     float x0, y0, width, height; // the TIGHT frame: the uploaded bounding box plus a margin
     float two_r, cell_min;      // cells are never smaller than cell_min (what the arrays were sized for)
@@ -427,8 +428,9 @@ struct SbGridGeom {
     uint32_t nx, ny;
     float x0, y0;
     uint32_t wide;
+    uint32_t gen; // number of the build the current hash came from (SbGridCtl::builds)
 };
-#define SB_SCAN_BLOCK 2048u
+#define SB_CHAIN_END 0xFFFFFFFFu
 #define SB_MAX_WAVES 16
 #define SB_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SB_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -444,6 +446,7 @@ SB_DEV SbGridGeom sb_grid_geom_load(const SbGridCtl *c)
     m.x0 = SB_AGENT_LOAD(&c->x0);
     m.y0 = SB_AGENT_LOAD(&c->y0);
     m.wide = SB_AGENT_LOAD(&c->wide);
+    m.gen = SB_AGENT_LOAD(&c->builds);
     return m;
 }
 // the geometry that goes with a skin (every workgroup of k_grid_maintain computes the same values)
@@ -452,6 +455,7 @@ SB_DEV SbGridGeom sb_grid_geom_for(const SbGrid &g, float skin, uint32_t wide)
     SbGridGeom m;
     m.skin = skin;
     m.wide = wide;
+    m.gen = 0u; // (the builder fills it in)
     const float reach = g.two_r + 2.0f * skin;
     m.reach2 = reach * reach * 1.001f;
     const float want = g.two_r * 1.015625f + 2.0f * skin;
@@ -522,32 +526,61 @@ SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
     return (uint32_t)q;
 }
 
-// record ranges of the three cell rows around a (stale) cell
-struct SbGridRanges {
-    uint32_t b[3], e[3];
+// The hash is a linked list per cell (r02; round 1 counted, scanned and scattered into cell-sorted records: three
+// device-wide barriers and a scan over every cell, 70-90 us per build against ~20 for one pass of exchanges): the first
+// records of the 3x3 cells around a (stale) cell, SB_CHAIN_END where a cell is empty or off the grid.
+struct SbGridHood {
+    uint32_t head[9];
 };
-SB_DEV SbGridRanges sb_grid_ranges(const SbGrid &g, const SbGridGeom &m, uint32_t cell)
+SB_DEV SbGridHood sb_grid_hood(const SbGrid &g, const SbGridGeom &m, uint32_t cell)
 {
-    SbGridRanges rg;
-    const uint32_t cx = cell % m.nx, cy = cell / m.nx;
-    const uint32_t xa = cx > 0u ? cx - 1u : 0u, xb = cx + 1u < m.nx ? cx + 1u : m.nx - 1u;
+    SbGridHood h;
+    const int cx = (int)(cell % m.nx), cy = (int)(cell / m.nx);
+    unsigned long long v[9];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int yy = (int)cy + r - 1;
-        const bool in = yy >= 0 && yy < (int)m.ny;
-        const uint32_t row = in ? (uint32_t)yy * m.nx : 0u;
-        const uint32_t b = g.cell_start[row + xa], e = g.cell_start[row + xb + 1u]; // one spare entry at the end
-        rg.b[r] = in ? b : 0u;
-        rg.e[r] = in ? e : 0u;
+    for (int k = 0; k < 9; k++) {
+        const int yy = cy + k / 3 - 1, xx = cx + k % 3 - 1;
+        const bool in = yy >= 0 && yy < (int)m.ny && xx >= 0 && xx < (int)m.nx;
+        v[k] = in ? g.head[(uint32_t)yy * m.nx + (uint32_t)xx] : 0ull; // nine independent loads
     }
-    return rg;
+#pragma unroll
+    for (int k = 0; k < 9; k++) h.head[k] = (uint32_t)(v[k] >> 32) == m.gen ? (uint32_t)v[k] : SB_CHAIN_END; // (gen >= 1: 0 is never current)
+    return h;
+}
+// f(x, y, slot, id) for every record of the nine chains; three chains are walked side by side so that their loads overlap
+template <typename F>
+SB_DEV void sb_grid_walk(const SbGrid &g, const SbGridHood &h, F f)
+{
+#pragma unroll 1
+    for (int r = 0; r < 3; r++) {
+#ifdef SB_HOOD_SELECT
+        uint32_t cur[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) cur[c] = r == 0 ? h.head[c] : (r == 1 ? h.head[3 + c] : h.head[6 + c]);
+#else
+        uint32_t cur[3] = {h.head[3 * r], h.head[3 * r + 1], h.head[3 * r + 2]};
+#endif
+        while ((cur[0] & cur[1] & cur[2]) != SB_CHAIN_END) { // all ones only when all three have ended
+            float4 rc[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (cur[c] != SB_CHAIN_END) rc[c] = g.rec[cur[c]];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (cur[c] != SB_CHAIN_END) {
+                    const uint32_t id = cur[c];
+                    cur[c] = __float_as_uint(rc[c].w);
+                    f(rc[c].x, rc[c].y, __float_as_uint(rc[c].z), id);
+                }
+        }
+    }
 }
 
 // The collision loop of compute.wgsl:144-170 restricted to the 3x3 cell neighbourhood, applying
 // contacts in ASCENDING SLOT ORDER exactly like the all-pairs scan does: repeatedly pick the
 // contact with the smallest slot above the last one applied.  Non-contacts are no-ops in the
 // reference loop, so skipping them changes nothing; the result is bit-identical to all-pairs.
-SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRanges &rg, const SbParams &prm, float friction,
+SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridHood &hood, const SbParams &prm, float friction,
                             float elasticity_coeff, SbParticle &particle, const SbParticle &self, uint32_t i,
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
                             const float2 *__restrict__ vel_r)
@@ -563,40 +596,28 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRa
         // one sweep collects the FOUR contacts with the smallest slots above `last` (sorted insert into four
         // registers); they are then applied in that order.  A pile of K contacts costs K/4 sweeps, not K.
         uint32_t bs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bi[4] = {0u, 0u, 0u, 0u};
+        sb_grid_walk(g, hood, [&](float rx, float ry, uint32_t slot, uint32_t id) {
+            if (id == i || (have_last && slot <= last) || slot >= bs[3]) return;
+            const float sx = rx - qx, sy = ry - qy;
+            if (sx * sx + sy * sy > stale_far2) return; // cannot have come within 2r (see SbGridCtl)
+            const float2 q = pos_r[id];
+            const float ex = q.x - self.p.x, ey = q.y - self.p.y;
+            const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
+            // sqrt is monotone: d2 clearly above (2r)^2 cannot give d < 2r (and is not 0), so the
+            // correctly rounded root is only evaluated for the few candidates near contact range
+            if (d2 > far2) return;
+            const float d = sb_sqrt(d2);
+            if (!(d == 0.0f || d < two_r)) return;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            for (uint32_t k0 = rg.b[r]; k0 < rg.e[r]; k0 += 4u) {
-                float4 rc[4]; // records are consecutive: fetch four at a time, then test
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    rc[j] = (k0 + (uint32_t)j < rg.e[r]) ? g.rec[k0 + (uint32_t)j]
-                                                         : make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t slot = __float_as_uint(rc[j].z), id = __float_as_uint(rc[j].w);
-                    if (id == i || (have_last && slot <= last) || slot >= bs[3]) continue;
-                    const float sx = rc[j].x - qx, sy = rc[j].y - qy;
-                    if (sx * sx + sy * sy > stale_far2) continue; // cannot have come within 2r (see SbGridCtl)
-                    const float2 q = pos_r[id];
-                    const float ex = q.x - self.p.x, ey = q.y - self.p.y;
-                    const float d2 = ex * ex + ey * ey; // exactly the argument length() takes the root of
-                    // sqrt is monotone: d2 clearly above (2r)^2 cannot give d < 2r (and is not 0), so the
-                    // correctly rounded root is only evaluated for the few candidates near contact range
-                    if (d2 > far2) continue;
-                    const float d = sb_sqrt(d2);
-                    if (!(d == 0.0f || d < two_r)) continue;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) { // carry the larger one down the four registers
-                        const bool lt = slot < bs[q4];
-                        const uint32_t ts = lt ? bs[q4] : slot, ti = lt ? bi[q4] : id;
-                        bs[q4] = lt ? slot : bs[q4];
-                        bi[q4] = lt ? id : bi[q4];
-                        slot = ts;
-                        id = ti;
-                    }
-                }
+            for (int q4 = 0; q4 < 4; q4++) { // carry the larger one down the four registers
+                const bool lt = slot < bs[q4];
+                const uint32_t ts = lt ? bs[q4] : slot, ti = lt ? bi[q4] : id;
+                bs[q4] = lt ? slot : bs[q4];
+                bi[q4] = lt ? id : bi[q4];
+                slot = ts;
+                id = ti;
             }
-        }
+        });
         bool full = true;
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
@@ -620,32 +641,27 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridRa
 SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, uint32_t i, float2 p)
 {
     const float reach2 = m.reach2;
-    const SbGridRanges rg = sb_grid_ranges(g, m, g.cell_of[i]);
+    const SbGridHood hood = sb_grid_hood(g, m, g.cell_of[i]);
     uint32_t n = 0u, last = 0u;
     bool have_last = false;
     for (;;) {
         // one sweep over the candidates collects the FOUR smallest slots above `last` (sorted insert into four
         // registers), so a typical list of 4-8 entries costs two or three sweeps instead of one per entry
         uint32_t bs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bi[4] = {0u, 0u, 0u, 0u};
+        sb_grid_walk(g, hood, [&](float rx, float ry, uint32_t slot, uint32_t id) {
+            if (id == i || (have_last && slot <= last) || slot >= bs[3]) return;
+            const float dx = rx - p.x, dy = ry - p.y;
+            if (dx * dx + dy * dy > reach2) return;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            for (uint32_t k = rg.b[r]; k < rg.e[r]; k++) {
-                const float4 rc = g.rec[k];
-                uint32_t slot = __float_as_uint(rc.z), id = __float_as_uint(rc.w);
-                if (id == i || (have_last && slot <= last) || slot >= bs[3]) continue;
-                const float dx = rc.x - p.x, dy = rc.y - p.y;
-                if (dx * dx + dy * dy > reach2) continue;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { // carry the larger one down the four registers
-                    const bool lt = slot < bs[q];
-                    const uint32_t ts = lt ? bs[q] : slot, ti = lt ? bi[q] : id;
-                    bs[q] = lt ? slot : bs[q];
-                    bi[q] = lt ? id : bi[q];
-                    slot = ts;
-                    id = ti;
-                }
+            for (int q = 0; q < 4; q++) { // carry the larger one down the four registers
+                const bool lt = slot < bs[q];
+                const uint32_t ts = lt ? bs[q] : slot, ti = lt ? bi[q] : id;
+                bs[q] = lt ? slot : bs[q];
+                bi[q] = lt ? id : bi[q];
+                slot = ts;
+                id = ti;
             }
-        }
+        });
         bool full = true;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -725,8 +741,8 @@ SB_DEV void sb_collide_slow(const SbGrid &g, bool fresh, const SbParams &prm, fl
     const SbGridGeom m = sb_grid_geom_load(g.ctl); // only these paths need the geometry of the current hash
     const uint32_t count = fresh ? sb_neighbour_list_build(g, m, i, self.p) : g.nl_count[i];
     if (count == SB_NL_OVERFLOW) {
-        const SbGridRanges rg = sb_grid_ranges(g, m, g.cell_of[i]);
-        sb_collide_grid(g, m, rg, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
+        const SbGridHood hood = sb_grid_hood(g, m, g.cell_of[i]);
+        sb_collide_grid(g, m, hood, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
     } else {
         sb_collide_list(g, count, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
     }
