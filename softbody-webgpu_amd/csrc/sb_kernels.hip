@@ -88,7 +88,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         }
     }
     if (MODE == SB_COLLIDE_GRID && active) {
-        sb_collide_slow(grid, SB_AGENT_LOAD(&grid.ctl->rebuild) != 0u, prm, c.friction, elasticity_coeff, particle, self, i,
+        sb_collide_slow(grid, SB_CTL_LOAD(&grid.ctl->rebuild) != 0u, prm, c.friction, elasticity_coeff, particle, self, i,
                         pidx, r.pos, r.vel);
     }
     float moved = 0.0f;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         sb_particle_finish(prm, c, particle, f.x, f.y);
         if (MODE == SB_COLLIDE_GRID) {
             const float dx = particle.p.x - self.p.x, dy = particle.p.y - self.p.y;
-            moved = fmaxf(sb_abs(dx - SB_AGENT_LOAD(&grid.ctl->cx)), sb_abs(dy - SB_AGENT_LOAD(&grid.ctl->cy))) * 1.4142137f;
+            moved = fmaxf(sb_abs(dx - SB_CTL_LOAD(&grid.ctl->cx)), sb_abs(dy - SB_CTL_LOAD(&grid.ctl->cy))) * 1.4142137f;
             if (threadIdx.x == 0) sb_store_sample_displacement(blk_max, gridDim.x, dx, dy);
         }
     }
@@ -213,9 +213,9 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
     bool fresh = false;
     float drift_x = 0.0f, drift_y = 0.0f; // SbGridCtl: the common displacement this substep is measured against
     if (MODE == SB_COLLIDE_GRID) {
-        fresh = SB_AGENT_LOAD(&grid.ctl->rebuild) != 0u;
-        drift_x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_AGENT_LOAD(&grid.ctl->cx)))); // uniform: SGPRs
-        drift_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_AGENT_LOAD(&grid.ctl->cy))));
+        fresh = SB_CTL_LOAD(&grid.ctl->rebuild) != 0u;
+        drift_x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_CTL_LOAD(&grid.ctl->cx)))); // uniform: SGPRs
+        drift_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_CTL_LOAD(&grid.ctl->cy))));
 #pragma unroll
         for (int u = 0; u < SB_UNROLL; u++) {
             const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
@@ -436,13 +436,13 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     const uint32_t tid = threadIdx.x;
     // ---- decision, identical in every workgroup (everything read here was written by earlier launches)
     const SbGridCtl *cin = ctl + par;
-    const float skin = SB_AGENT_LOAD(&cin->skin), accum_in = SB_AGENT_LOAD(&cin->accum); // in flight with the slots
-    const uint32_t builds = SB_AGENT_LOAD(&cin->builds), force = SB_AGENT_LOAD(&cin->force);
-    const float c_used_x = SB_AGENT_LOAD(&cin->cx), c_used_y = SB_AGENT_LOAD(&cin->cy); // what the last substep used
-    const float C_in_x = SB_AGENT_LOAD(&cin->Cx), C_in_y = SB_AGENT_LOAD(&cin->Cy);
+    const float skin = SB_CTL_LOAD(&cin->skin), accum_in = SB_CTL_LOAD(&cin->accum); // in flight with the slots
+    const uint32_t builds = SB_CTL_LOAD(&cin->builds), force = SB_CTL_LOAD(&cin->force);
+    const float c_used_x = SB_CTL_LOAD(&cin->cx), c_used_y = SB_CTL_LOAD(&cin->cy); // what the last substep used
+    const float C_in_x = SB_CTL_LOAD(&cin->Cx), C_in_y = SB_CTL_LOAD(&cin->Cy);
     const SbGridGeom geom_in = sb_grid_geom_load(cin);
-    const uint32_t since = SB_AGENT_LOAD(&cin->since);
-    const float skin_min = SB_AGENT_LOAD(&cin->skin_min), skin_max = SB_AGENT_LOAD(&cin->skin_max);
+    const uint32_t since = SB_CTL_LOAD(&cin->since);
+    const float skin_min = SB_CTL_LOAD(&cin->skin_min), skin_max = SB_CTL_LOAD(&cin->skin_max);
     float m = 0.0f, sx = 0.0f, sy = 0.0f;
     for (uint32_t i = tid; i < nblk; i += SB_MT) { // per-lane addresses: vector loads
         m = fmaxf(m, __uint_as_float(blk_max[i]));
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
     }
     // the frame: tight until the build before this one found more than 1/64 of the particles outside it (that build's
     // block 0 published the verdict in wide_next; every workgroup of this launch reads the same word)
-    const uint32_t wide_next_in = SB_AGENT_LOAD(&cin->wide_next);
+    const uint32_t wide_next_in = SB_CTL_LOAD(&cin->wide_next);
     const uint32_t wide = (geom_in.wide != 0u || wide_next_in != 0u) ? 1u : 0u;
     const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new, wide) : geom_in;
     // the common displacement the coming substep is measured against: the mean of the one just done

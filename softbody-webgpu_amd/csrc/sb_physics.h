@@ -386,6 +386,9 @@ struct SbGrid {
     const struct SbGridCtl *ctl; // what the k_grid_maintain launch just before this kernel published
 };
 #define SB_NL_CAP 16u
+#ifndef SB_NL_SEL
+#define SB_NL_SEL 6 // candidates one sweep of the list builder can take
+#endif
 #define SB_NL_OVERFLOW 0xFFFFFFFFu
 // The hash is rebuilt only when needed.  Cells are 2r*(1+1/64) + 2*skin wide; the engine keeps a bound
 // D on how far any particle can have moved since the last build RELATIVE TO THE COMMON DRIFT C of the scene,
@@ -433,20 +436,24 @@ struct SbGridGeom {
 #define SB_CHAIN_END 0xFFFFFFFFu
 #define SB_MAX_WAVES 16
 #define SB_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// SbGridCtl words are written by ONE launch (k_grid_maintain) and read by LATER launches only: the readers use plain loads
+// (a uniform address: scalar loads through the constant cache, invalidated at every kernel start) -- an agent-scope atomic
+// load per word and per particle was a trip past the L2 each
+#define SB_CTL_LOAD(p) (*(p))
 #define SB_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 SB_DEV SbGridGeom sb_grid_geom_load(const SbGridCtl *c)
 {
     SbGridGeom m;
-    m.skin = SB_AGENT_LOAD(&c->skin);
-    m.cell = SB_AGENT_LOAD(&c->cell);
-    m.reach2 = SB_AGENT_LOAD(&c->reach2);
-    m.nx = SB_AGENT_LOAD(&c->nx);
-    m.ny = SB_AGENT_LOAD(&c->ny);
-    m.x0 = SB_AGENT_LOAD(&c->x0);
-    m.y0 = SB_AGENT_LOAD(&c->y0);
-    m.wide = SB_AGENT_LOAD(&c->wide);
-    m.gen = SB_AGENT_LOAD(&c->builds);
+    m.skin = SB_CTL_LOAD(&c->skin);
+    m.cell = SB_CTL_LOAD(&c->cell);
+    m.reach2 = SB_CTL_LOAD(&c->reach2);
+    m.nx = SB_CTL_LOAD(&c->nx);
+    m.ny = SB_CTL_LOAD(&c->ny);
+    m.x0 = SB_CTL_LOAD(&c->x0);
+    m.y0 = SB_CTL_LOAD(&c->y0);
+    m.wide = SB_CTL_LOAD(&c->wide);
+    m.gen = SB_CTL_LOAD(&c->builds);
     return m;
 }
 // the geometry that goes with a skin (every workgroup of k_grid_maintain computes the same values)
@@ -548,18 +555,40 @@ SB_DEV SbGridHood sb_grid_hood(const SbGrid &g, const SbGridGeom &m, uint32_t ce
     return h;
 }
 // f(x, y, slot, id) for every record of the nine chains; three chains are walked side by side so that their loads overlap
+#ifndef SB_WALK_WIDTH
+#define SB_WALK_WIDTH 3
+#endif
 template <typename F>
 SB_DEV void sb_grid_walk(const SbGrid &g, const SbGridHood &h, F f)
 {
+#if SB_WALK_WIDTH == 9
+    uint32_t cur[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) cur[c] = h.head[c];
+    for (;;) {
+        uint32_t all = 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < 9; c++) all &= cur[c];
+        if (all == SB_CHAIN_END) break;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float4 rc[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (cur[3 * r + c] != SB_CHAIN_END) rc[c] = g.rec[cur[3 * r + c]];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (cur[3 * r + c] != SB_CHAIN_END) {
+                    const uint32_t id = cur[3 * r + c];
+                    cur[3 * r + c] = __float_as_uint(rc[c].w);
+                    f(rc[c].x, rc[c].y, __float_as_uint(rc[c].z), id);
+                }
+        }
+    }
+#else
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
-#ifdef SB_HOOD_SELECT
-        uint32_t cur[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) cur[c] = r == 0 ? h.head[c] : (r == 1 ? h.head[3 + c] : h.head[6 + c]);
-#else
         uint32_t cur[3] = {h.head[3 * r], h.head[3 * r + 1], h.head[3 * r + 2]};
-#endif
         while ((cur[0] & cur[1] & cur[2]) != SB_CHAIN_END) { // all ones only when all three have ended
             float4 rc[3];
 #pragma unroll
@@ -574,6 +603,7 @@ SB_DEV void sb_grid_walk(const SbGrid &g, const SbGridHood &h, F f)
                 }
         }
     }
+#endif
 }
 
 // The collision loop of compute.wgsl:144-170 restricted to the 3x3 cell neighbourhood, applying
@@ -589,7 +619,7 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridHo
     const float far2 = two_r * two_r * 1.001f;
     const float reach = two_r + m.skin, stale_far2 = reach * reach * 1.001f;
     // where this particle would be in the frame of the build: current position minus the common drift
-    const float qx = self.p.x - SB_AGENT_LOAD(&g.ctl->Cx), qy = self.p.y - SB_AGENT_LOAD(&g.ctl->Cy);
+    const float qx = self.p.x - SB_CTL_LOAD(&g.ctl->Cx), qy = self.p.y - SB_CTL_LOAD(&g.ctl->Cy);
     bool have_last = false;
     uint32_t last = 0u;
     for (;;) {
@@ -645,15 +675,17 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
     uint32_t n = 0u, last = 0u;
     bool have_last = false;
     for (;;) {
-        // one sweep over the candidates collects the FOUR smallest slots above `last` (sorted insert into four
-        // registers), so a typical list of 4-8 entries costs two or three sweeps instead of one per entry
-        uint32_t bs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bi[4] = {0u, 0u, 0u, 0u};
+        // one sweep over the candidates collects the SB_NL_SEL smallest slots above `last` (sorted insert into that many
+        // registers), so a typical list of 4-7 entries costs one sweep, not one per entry
+        uint32_t bs[SB_NL_SEL], bi[SB_NL_SEL];
+#pragma unroll
+        for (int q = 0; q < SB_NL_SEL; q++) bs[q] = 0xFFFFFFFFu, bi[q] = 0u;
         sb_grid_walk(g, hood, [&](float rx, float ry, uint32_t slot, uint32_t id) {
-            if (id == i || (have_last && slot <= last) || slot >= bs[3]) return;
+            if (id == i || (have_last && slot <= last) || slot >= bs[SB_NL_SEL - 1]) return;
             const float dx = rx - p.x, dy = ry - p.y;
             if (dx * dx + dy * dy > reach2) return;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { // carry the larger one down the four registers
+            for (int q = 0; q < SB_NL_SEL; q++) { // carry the larger one down the four registers
                 const bool lt = slot < bs[q];
                 const uint32_t ts = lt ? bs[q] : slot, ti = lt ? bi[q] : id;
                 bs[q] = lt ? slot : bs[q];
@@ -664,7 +696,7 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
         });
         bool full = true;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < SB_NL_SEL; q++) {
             if (bs[q] == 0xFFFFFFFFu) {
                 full = false;
             } else if (n != SB_NL_OVERFLOW) {
@@ -678,7 +710,7 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
                 }
             }
         }
-        if (!full || n == SB_NL_OVERFLOW) break; // fewer than four left above `last`: that was everybody
+        if (!full || n == SB_NL_OVERFLOW) break; // fewer than SB_NL_SEL left above `last`: that was everybody
     }
     g.nl_count[i] = n;
     return n;

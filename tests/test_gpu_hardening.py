@@ -15,9 +15,10 @@ OVERSUBSCRIBED = r"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "oracle"))
 import __graft_entry__ as ge
+import oracle
 sb = ge.load_package()
-from oracle import oracle
 # 2.3 M free particles: 563 workgroups of 4096 particles wanted, 2048 allowed -> more than the 256 x 2 the card holds at once
 buf = sb.scenes.soup_buffers(1520, 1520, d=24.0, origin=(30.0, 30.0), jitter=1.5, speed=20.0)
 eng = sb.Engine(bounds_size=40000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=2)
