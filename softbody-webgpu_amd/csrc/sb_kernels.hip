@@ -416,7 +416,9 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 // ctl[par] / blk_max[par] and publishes ctl[par^1]; the particle kernel that follows fills blk_max[par^1].
 #define SB_MAINTAIN_BLOCKS 64u // (measured on the 1 M pile: 64 -> 41.5, 128 -> 42.2, 256..1024 -> 44.7-45.0 us per substep;
                               // the launch runs on every substep and only rebuilds on one in 4-14)
+#ifndef SB_MT
 #define SB_MT 1024u // threads per workgroup of k_grid_maintain
+#endif
 
 struct SbGridBuild {
     unsigned long long *head;

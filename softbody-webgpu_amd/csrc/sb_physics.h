@@ -555,55 +555,30 @@ SB_DEV SbGridHood sb_grid_hood(const SbGrid &g, const SbGridGeom &m, uint32_t ce
     return h;
 }
 // f(x, y, slot, id) for every record of the nine chains; three chains are walked side by side so that their loads overlap
-#ifndef SB_WALK_WIDTH
-#define SB_WALK_WIDTH 3
-#endif
+// f(x, y, slot, id) for every record of the nine chains; three chains are walked side by side so that their loads overlap.
+// Branch-free inside a round: a chain that has ended re-reads `self` (the caller's own record, which every f ignores anyway:
+// a particle is not its own neighbour) instead of masking its load off -- exec-mask bookkeeping around every load and every
+// early return made the list builder instruction-bound (r02 counters: 1300 VALU + 650 SALU per particle and sweep).
 template <typename F>
-SB_DEV void sb_grid_walk(const SbGrid &g, const SbGridHood &h, F f)
+SB_DEV void sb_grid_walk(const SbGrid &g, const SbGridHood &h, uint32_t self, F f)
 {
-#if SB_WALK_WIDTH == 9
-    uint32_t cur[9];
-#pragma unroll
-    for (int c = 0; c < 9; c++) cur[c] = h.head[c];
-    for (;;) {
-        uint32_t all = 0xFFFFFFFFu;
-#pragma unroll
-        for (int c = 0; c < 9; c++) all &= cur[c];
-        if (all == SB_CHAIN_END) break;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            float4 rc[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                if (cur[3 * r + c] != SB_CHAIN_END) rc[c] = g.rec[cur[3 * r + c]];
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                if (cur[3 * r + c] != SB_CHAIN_END) {
-                    const uint32_t id = cur[3 * r + c];
-                    cur[3 * r + c] = __float_as_uint(rc[c].w);
-                    f(rc[c].x, rc[c].y, __float_as_uint(rc[c].z), id);
-                }
-        }
-    }
-#else
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
         uint32_t cur[3] = {h.head[3 * r], h.head[3 * r + 1], h.head[3 * r + 2]};
         while ((cur[0] & cur[1] & cur[2]) != SB_CHAIN_END) { // all ones only when all three have ended
+            uint32_t id[3];
             float4 rc[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-                if (cur[c] != SB_CHAIN_END) rc[c] = g.rec[cur[c]];
+            for (int c = 0; c < 3; c++) id[c] = cur[c] != SB_CHAIN_END ? cur[c] : self;
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-                if (cur[c] != SB_CHAIN_END) {
-                    const uint32_t id = cur[c];
-                    cur[c] = __float_as_uint(rc[c].w);
-                    f(rc[c].x, rc[c].y, __float_as_uint(rc[c].z), id);
-                }
+            for (int c = 0; c < 3; c++) rc[c] = g.rec[id[c]];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                cur[c] = cur[c] != SB_CHAIN_END ? __float_as_uint(rc[c].w) : SB_CHAIN_END;
+                f(rc[c].x, rc[c].y, __float_as_uint(rc[c].z), id[c]);
+            }
         }
     }
-#endif
 }
 
 // The collision loop of compute.wgsl:144-170 restricted to the 3x3 cell neighbourhood, applying
@@ -626,7 +601,7 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridHo
         // one sweep collects the FOUR contacts with the smallest slots above `last` (sorted insert into four
         // registers); they are then applied in that order.  A pile of K contacts costs K/4 sweeps, not K.
         uint32_t bs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bi[4] = {0u, 0u, 0u, 0u};
-        sb_grid_walk(g, hood, [&](float rx, float ry, uint32_t slot, uint32_t id) {
+        sb_grid_walk(g, hood, i, [&](float rx, float ry, uint32_t slot, uint32_t id) {
             if (id == i || (have_last && slot <= last) || slot >= bs[3]) return;
             const float sx = rx - qx, sy = ry - qy;
             if (sx * sx + sy * sy > stale_far2) return; // cannot have come within 2r (see SbGridCtl)
@@ -680,10 +655,10 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
         uint32_t bs[SB_NL_SEL], bi[SB_NL_SEL];
 #pragma unroll
         for (int q = 0; q < SB_NL_SEL; q++) bs[q] = 0xFFFFFFFFu, bi[q] = 0u;
-        sb_grid_walk(g, hood, [&](float rx, float ry, uint32_t slot, uint32_t id) {
-            if (id == i || (have_last && slot <= last) || slot >= bs[SB_NL_SEL - 1]) return;
+        sb_grid_walk(g, hood, i, [&](float rx, float ry, uint32_t slot, uint32_t id) {
             const float dx = rx - p.x, dy = ry - p.y;
-            if (dx * dx + dy * dy > reach2) return;
+            // (one test, no short-circuit branches)
+            if ((id == i) | (have_last & (slot <= last)) | (slot >= bs[SB_NL_SEL - 1]) | (dx * dx + dy * dy > reach2)) return;
 #pragma unroll
             for (int q = 0; q < SB_NL_SEL; q++) { // carry the larger one down the four registers
                 const bool lt = slot < bs[q];
