@@ -73,6 +73,20 @@ struct SbStageTimer {
     }
 };
 
+// The plan of an upload lives in a few hundred megabytes of host arrays; handing them back to the kernel (munmap) took 40 ms of
+// a 140 ms upload.  They are moved here and destroyed on a side thread, which the next upload or sb_destroy joins.
+struct SbUploadTrash {
+    std::vector<float> px, py;
+    SbTiling tl;
+    SbBlocking bl;
+    SbHostBeams hb;
+    std::vector<uint32_t> v[8];
+};
+static void reap_join(sb_engine *e)
+{
+    if (e->reaper.joinable()) e->reaper.join();
+}
+
 static void free_scene(sb_engine *e)
 {
     for (void *p : e->allocs) (void)hipFree(p);
@@ -122,62 +136,177 @@ static inline uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); 
 struct SbMatDict {
     uint32_t mode = 0;
     std::vector<float> table; // [rows][6] = length, spring, damp, yield, limit, 1/length
-    std::vector<uint32_t> of_slot;
+    sbt::uvec<uint32_t> of_slot;
 };
-static void build_material_dictionary(SbMatDict &d, const std::vector<SbHostBeam> &hb, uint32_t cap)
+static void build_material_dictionary(SbMatDict &d, const SbHostBeams &hb, uint32_t cap)
 {
     const uint32_t B = (uint32_t)hb.size();
     struct Key { uint32_t w[5]; bool operator==(const Key &o) const { return memcmp(w, o.w, sizeof w) == 0; } };
     struct KeyHash { size_t operator()(const Key &k) const { size_t h = 1469598103934665603ull; for (uint32_t x : k.w) h = (h ^ x) * 1099511628211ull; return h; } };
-    d.of_slot.assign(B, 0);
+    // a few host threads over contiguous slot ranges, each with its own small dictionary (provisional row numbers); the rows
+    // are then numbered by the first slot that uses them, i.e. exactly as one thread walking the slots in order would
+    struct Local {
+        std::unordered_map<Key, uint32_t, KeyHash> dict;
+        std::vector<Key> keys;
+        std::vector<uint32_t> first, remap;
+        uint32_t lo = 0, hi = 0;
+        bool ok = true;
+    };
+    d.of_slot.resize(B);
     d.mode = 0;
     d.table.clear();
     for (int mode = 2; mode >= 1 && cap; mode--) {
-        std::unordered_map<Key, uint32_t, KeyHash> dict;
+        std::vector<Local> loc(16); // (parallel_tiles uses at most 16 workers)
+        sbt::parallel_tiles(B, [&](uint32_t w, uint32_t s0, uint32_t s1) {
+            Local &l = loc[w];
+            l.lo = s0;
+            l.hi = s1;
+            bool have_last = false;
+            Key last_key{};
+            uint32_t last_row = 0;
+            for (uint32_t s = s0; s < s1; s++) {
+                Key k;
+                const float *f = hb[s].f; // length, target, last, spring, damp, yield, limit
+                float row[5] = {mode == 2 ? f[0] : 0.0f, f[3], f[4], f[5], f[6]};
+                memcpy(k.w, row, sizeof row);
+                if (have_last && k == last_key) { // runs of one material are the rule: no hash lookup
+                    d.of_slot[s] = last_row;
+                    continue;
+                }
+                auto it = l.dict.find(k);
+                if (it == l.dict.end()) {
+                    if (l.dict.size() >= cap) {
+                        l.ok = false;
+                        return;
+                    }
+                    it = l.dict.emplace(k, (uint32_t)l.keys.size()).first;
+                    l.keys.push_back(k);
+                    l.first.push_back(s);
+                }
+                d.of_slot[s] = it->second;
+                last_key = k;
+                last_row = it->second;
+                have_last = true;
+            }
+        });
+        bool ok = true;
+        std::unordered_map<Key, uint32_t, KeyHash> first_of; // key -> lowest slot that uses it
+        for (const Local &l : loc) {
+            ok = ok && l.ok;
+            if (!ok) break;
+            for (size_t j = 0; j < l.keys.size(); j++) {
+                auto it = first_of.emplace(l.keys[j], l.first[j]).first;
+                it->second = std::min(it->second, l.first[j]);
+            }
+            if (first_of.size() > cap) ok = false;
+        }
+        if (!ok) continue;
+        std::vector<std::pair<uint32_t, Key>> rows;
+        for (const auto &kv : first_of) rows.emplace_back(kv.second, kv.first);
+        std::sort(rows.begin(), rows.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        std::unordered_map<Key, uint32_t, KeyHash> row_of;
         std::vector<float> table;
-        bool ok = true, have_last = false;
-        Key last_key{};
-        uint32_t last_row = 0;
-        for (uint32_t s = 0; s < B && ok; s++) {
-            Key k;
-            const float *f = hb[s].f; // length, target, last, spring, damp, yield, limit
-            float row[5] = {mode == 2 ? f[0] : 0.0f, f[3], f[4], f[5], f[6]};
-            memcpy(k.w, row, sizeof row);
-            if (have_last && k == last_key) { // runs of one material are the rule: no hash lookup
-                d.of_slot[s] = last_row;
-                continue;
-            }
-            auto it = dict.find(k);
-            if (it == dict.end()) {
-                if (dict.size() >= cap) { ok = false; break; }
-                it = dict.emplace(k, (uint32_t)dict.size()).first;
-                table.insert(table.end(), row, row + 5);
-                table.push_back(mode == 2 ? 1.0f / row[0] : 0.0f); // 1 / length: one IEEE divide per material
-            }
-            d.of_slot[s] = it->second;
-            last_key = k;
-            last_row = it->second;
-            have_last = true;
+        for (const auto &r : rows) {
+            row_of.emplace(r.second, (uint32_t)row_of.size());
+            float row[5];
+            memcpy(row, r.second.w, sizeof row);
+            table.insert(table.end(), row, row + 5);
+            table.push_back(mode == 2 ? 1.0f / row[0] : 0.0f); // 1 / length: one IEEE divide per material
         }
-        if (ok) {
-            d.mode = (uint32_t)mode;
-            d.table.swap(table);
-            return;
+        for (Local &l : loc) {
+            l.remap.resize(l.keys.size());
+            for (size_t j = 0; j < l.keys.size(); j++) l.remap[j] = row_of[l.keys[j]];
         }
+        sbt::parallel_tiles(B, [&](uint32_t w, uint32_t s0, uint32_t s1) {
+            const Local &l = loc[w];
+            for (uint32_t s = s0; s < s1; s++) d.of_slot[s] = l.remap[d.of_slot[s]];
+        });
+        d.mode = (uint32_t)mode;
+        d.table.swap(table);
+        return;
     }
 }
 
-template <typename T>
-static sb_status dev_upload(sb_engine *e, T **p, const std::vector<T> &v)
+// ---- pinned staging (see sb_engine.h).  stage_put: host -> device; `fill(off, len, out)` writes bytes [off, off + len) of the
+// source into `out` (pinned); it is called once per chunk, in order, and may itself use several threads.
+#define SB_STAGE_CHUNK ((size_t)16 << 20)
+static sb_status stage_init(sb_engine *e)
+{
+    if (e->stage[0]) return SB_OK;
+    uint8_t *p = nullptr;
+    SB_HIP(e, hipHostMalloc((void **)&p, 2 * SB_STAGE_CHUNK, hipHostMallocDefault));
+    e->stage[0] = p;
+    e->stage[1] = p + SB_STAGE_CHUNK;
+    for (int k = 0; k < 2; k++) SB_HIP(e, hipEventCreateWithFlags(&e->stage_done[k], hipEventDisableTiming));
+    return SB_OK;
+}
+template <typename F>
+static sb_status stage_put(sb_engine *e, void *dst, size_t bytes, F fill)
+{
+    SB_TRY(stage_init(e));
+    for (size_t off = 0; off < bytes; off += SB_STAGE_CHUNK) {
+        const int b = e->stage_cur;
+        e->stage_cur ^= 1;
+        if (e->stage_busy[b]) SB_HIP(e, hipEventSynchronize(e->stage_done[b]));
+        const size_t len = std::min(SB_STAGE_CHUNK, bytes - off);
+        fill(off, len, e->stage[b]);
+        SB_HIP(e, hipMemcpyAsync((uint8_t *)dst + off, e->stage[b], len, hipMemcpyHostToDevice, e->stream));
+        SB_HIP(e, hipEventRecord(e->stage_done[b], e->stream));
+        e->stage_busy[b] = true;
+    }
+    return SB_OK;
+}
+// a host array as it is
+static sb_status stage_put_bytes(sb_engine *e, void *dst, const void *src, size_t bytes)
+{
+    return stage_put(e, dst, bytes, [&](size_t off, size_t len, uint8_t *out) {
+        sbt::parallel_ranges(len, (size_t)1 << 20, [&](size_t a, size_t b) { memcpy(out + a, (const uint8_t *)src + off + a, b - a); });
+    });
+}
+// device -> host, `drain(off, len, in)` consumes bytes [off, off + len) from `in` (pinned); chunk k is drained while k + 1 flies
+template <typename F>
+static sb_status stage_get(sb_engine *e, const void *src, size_t bytes, F drain)
+{
+    SB_TRY(stage_init(e));
+    for (int k = 0; k < 2; k++)
+        if (e->stage_busy[k]) {
+            SB_HIP(e, hipEventSynchronize(e->stage_done[k]));
+            e->stage_busy[k] = false;
+        }
+    const size_t n = (bytes + SB_STAGE_CHUNK - 1) / SB_STAGE_CHUNK;
+    auto issue = [&](size_t k) -> hipError_t {
+        const size_t off = k * SB_STAGE_CHUNK, len = std::min(SB_STAGE_CHUNK, bytes - off);
+        hipError_t r = hipMemcpyAsync(e->stage[k & 1], (const uint8_t *)src + off, len, hipMemcpyDeviceToHost, e->stream);
+        return r != hipSuccess ? r : hipEventRecord(e->stage_done[k & 1], e->stream);
+    };
+    if (n) SB_HIP(e, issue(0));
+    for (size_t k = 0; k < n; k++) {
+        SB_HIP(e, hipEventSynchronize(e->stage_done[k & 1]));
+        if (k + 1 < n) SB_HIP(e, issue(k + 1));
+        const size_t off = k * SB_STAGE_CHUNK;
+        drain(off, std::min(SB_STAGE_CHUNK, bytes - off), e->stage[k & 1]);
+    }
+    return SB_OK;
+}
+
+static sb_status stage_get_bytes(sb_engine *e, void *dst, const void *src, size_t bytes)
+{
+    return stage_get(e, src, bytes, [&](size_t off, size_t len, const uint8_t *in) {
+        sbt::parallel_ranges(len, (size_t)1 << 20, [&](size_t a, size_t b) { memcpy((uint8_t *)dst + off + a, in + a, b - a); });
+    });
+}
+
+template <typename T, typename A>
+static sb_status dev_upload(sb_engine *e, T **p, const std::vector<T, A> &v)
 {
     SB_TRY(dev_alloc(e, p, v.size()));
-    if (!v.empty()) SB_HIP(e, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) SB_TRY(stage_put_bytes(e, *p, v.data(), v.size() * sizeof(T)));
     return SB_OK;
 }
 
 // device side of the temporally blocked plan; on return blockK is 0 if the scene cannot use it (more material rows
 // than the 8 spare bits of an entry word address) and the caller falls back to the single-substep tiling
-static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::vector<SbHostBeam> &hb, uint32_t &blockK)
+static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHostBeams &hb, uint32_t &blockK, SbStageTimer &tm)
 {
     const uint32_t B = (uint32_t)hb.size(), T = bl.ntiles;
     SbMatDict md;
@@ -188,6 +317,7 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
         blockK = 0;
         return SB_OK;
     }
+    tm.mark("  material dictionary");
     SbBlockedDev &k = e->bk;
     k.K = blockK;
     k.cap = bl.max_region;
@@ -204,9 +334,9 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
     e->lbits = SB_BK_LBITS;
     e->nmat = (uint32_t)(md.table.size() / 6);
     e->nbeam = B;
-    e->h_copy_of_slot = bl.g_of_slot;
-    std::vector<uint32_t> words(bl.ent_la.size());
-    std::vector<float> lengths;
+    e->h_copy_of_slot.assign(bl.g_of_slot.begin(), bl.g_of_slot.end());
+    sbt::uvec<uint32_t> words(bl.ent_la.size());
+    sbt::uvec<float> lengths;
     if (md.mode == 1) lengths.resize(words.size());
     sbt::parallel_ranges(words.size(), 1 << 16, [&](size_t j0, size_t j1) {
         for (size_t j = j0; j < j1; j++) {
@@ -215,6 +345,7 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
             if (md.mode == 1) lengths[j] = hb[s].f[0];
         }
     });
+    tm.mark("  entry words");
     SB_TRY(dev_upload(e, &k.d_tile_p0, bl.tile_p0));
     SB_TRY(dev_upload(e, &k.d_tile_h0, bl.tile_h0));
     SB_TRY(dev_upload(e, &k.d_halo_idx, bl.halo_idx));
@@ -232,8 +363,9 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
     SB_TRY(dev_upload(e, &k.d_ent_length, lengths));
     SB_TRY(dev_upload(e, &e->d_mat, md.table));
     SB_TRY(dev_upload(e, &e->beams.slot, bl.beam_slot));
+    tm.mark("  plan arrays to device");
     // beam state, one entry per beam in owner order; buffer 0 = uploaded, buffer 1 = scratch
-    std::vector<float> tmp(B);
+    sbt::uvec<float> tmp(B);
     float **dst[4] = {&k.d_target[0], &k.d_last[0], &e->beams.strain, &e->beams.stress};
     const int field[4] = {1, 2, 7, 8};
     for (int a = 0; a < 4; a++) {
@@ -242,6 +374,7 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const std::v
         });
         SB_TRY(dev_upload(e, dst[a], tmp));
     }
+    tm.mark("  beam state to device");
     SB_TRY(dev_alloc(e, &k.d_target[1], B));
     SB_TRY(dev_alloc(e, &k.d_last[1], B));
     SB_HIP(e, hipMemset(k.d_target[1], 0, std::max<size_t>(B, 1) * 4));
@@ -341,8 +474,12 @@ sb_status sb_destroy(sb_engine *e)
     if (!e) return SB_ERR_INVALID;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    reap_join(e);
     free_scene(e);
     if (e->dev_err) (void)hipHostFree(e->dev_err);
+    if (e->stage[0]) (void)hipHostFree(e->stage[0]);
+    for (int k = 0; k < 2; k++)
+        if (e->stage_done[k]) (void)hipEventDestroy(e->stage_done[k]);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -376,6 +513,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
 
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
+    reap_join(e);
     free_scene(e);
 
     SbStageTimer tm;
@@ -399,7 +537,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         slot_index[s] = idx;
     }
     // ---- beams: slot -> record; endpoints must be active particles
-    std::vector<SbHostBeam> hb(B);
+    SbHostBeams hb(B);
     {
         // a few host threads over the beam slots; the first offence (lowest slot of its chunk) is reported
         std::vector<uint8_t> seen((size_t)maxB, 0);
@@ -457,10 +595,12 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     tm.mark("validate + beam records");
     // ---- internal particle order
     std::vector<float> px(P), py(P);
-    for (uint32_t s = 0; s < P; s++) {
-        memcpy(&px[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE, 4);
-        memcpy(&py[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE + 4, 4);
-    }
+    sbt::parallel_ranges(P, 1 << 16, [&](size_t s0, size_t s1) {
+        for (size_t s = s0; s < s1; s++) {
+            memcpy(&px[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE, 4);
+            memcpy(&py[s], pd + (size_t)slot_index[s] * SB_PARTICLE_STRIDE + 4, 4);
+        }
+    });
     SbTiling tl;
     SbBlocking bl;
     uint32_t blockK = 0; // > 0: the temporally blocked plan is in use (sb_blocking.h)
@@ -500,10 +640,14 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         std::iota(order.begin(), order.end(), 0u);
     }
     std::vector<uint32_t> internal_of_slot(P);
-    for (uint32_t i = 0; i < P; i++) internal_of_slot[order[i]] = i;
     e->h_pslot = order;
     e->h_pidx.resize(P);
-    for (uint32_t i = 0; i < P; i++) e->h_pidx[i] = slot_index[order[i]];
+    sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            internal_of_slot[order[i]] = (uint32_t)i;
+            e->h_pidx[i] = slot_index[order[i]];
+        }
+    });
 
     tm.mark("tiling / blocking plan");
     // ---- upload particles (A = data, B = zero: engineWorker.ts:588,593)
@@ -523,16 +667,16 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             SB_TRY(dev_alloc(e, &e->part[k].vel, P));
             SB_TRY(dev_alloc(e, &e->part[k].acc, P));
         }
-        SB_HIP(e, hipMemcpy(e->part[0].pos, hp.data(), P * sizeof(float2), hipMemcpyHostToDevice));
-        SB_HIP(e, hipMemcpy(e->part[0].vel, hv.data(), P * sizeof(float2), hipMemcpyHostToDevice));
-        SB_HIP(e, hipMemcpy(e->part[0].acc, ha.data(), P * sizeof(float2), hipMemcpyHostToDevice));
+        SB_TRY(stage_put_bytes(e, e->part[0].pos, hp.data(), P * sizeof(float2)));
+        SB_TRY(stage_put_bytes(e, e->part[0].vel, hv.data(), P * sizeof(float2)));
+        SB_TRY(stage_put_bytes(e, e->part[0].acc, ha.data(), P * sizeof(float2)));
         SB_HIP(e, hipMemset(e->part[1].pos, 0, std::max<size_t>(P, 1) * sizeof(float2)));
         SB_HIP(e, hipMemset(e->part[1].vel, 0, std::max<size_t>(P, 1) * sizeof(float2)));
         SB_HIP(e, hipMemset(e->part[1].acc, 0, std::max<size_t>(P, 1) * sizeof(float2)));
         SB_TRY(dev_alloc(e, &e->d_pidx, P));
         SB_TRY(dev_alloc(e, &e->d_pslot, P));
-        SB_HIP(e, hipMemcpy(e->d_pidx, e->h_pidx.data(), P * 4, hipMemcpyHostToDevice));
-        SB_HIP(e, hipMemcpy(e->d_pslot, e->h_pslot.data(), P * 4, hipMemcpyHostToDevice));
+        SB_TRY(stage_put_bytes(e, e->d_pidx, e->h_pidx.data(), (size_t)P * 4));
+        SB_TRY(stage_put_bytes(e, e->d_pslot, e->h_pslot.data(), (size_t)P * 4));
     }
 
     tm.mark("particles to device");
@@ -543,7 +687,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     e->bk = SbBlockedDev{};
     e->beams = SbBeamArrays{};
     if (blockK) {
-        SB_TRY(upload_blocked(e, bl, hb, blockK));
+        SB_TRY(upload_blocked(e, bl, hb, blockK, tm));
         if (!blockK) // no dictionary: the single-substep tiling after all (same bisection, hence the same particle order)
             sb_build_tiling(tl, px, py, hb, e->opt.tile_particles ? e->opt.tile_particles : 1024);
     }
@@ -578,44 +722,24 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         while ((1u << lbits) <= tl.max_all) lbits++; // all-ones local index stays free for the dead marker
         const uint32_t mbits = lbits >= 16 ? 0 : 32 - 2 * lbits;
         const uint32_t mat_cap = mbits == 0 ? 0 : std::min<uint32_t>(1u << std::min(mbits, 12u), 2048u);
-        struct Key { uint32_t w[5]; bool operator==(const Key &o) const { return memcmp(w, o.w, sizeof w) == 0; } };
-        struct KeyHash { size_t operator()(const Key &k) const { size_t h = 1469598103934665603ull; for (uint32_t x : k.w) h = (h ^ x) * 1099511628211ull; return h; } };
-        std::vector<uint32_t> mat_of_slot(B, 0);
-        e->mat_mode = 0;
-        for (int mode = 2; mode >= 1 && mat_cap; mode--) {
-            std::unordered_map<Key, uint32_t, KeyHash> dict;
-            std::vector<float> table;
-            bool ok = true;
-            for (uint32_t s = 0; s < B && ok; s++) {
-                Key k;
-                const float *f = hb[s].f; // length, target, last, spring, damp, yield, limit
-                float row[5] = {mode == 2 ? f[0] : 0.0f, f[3], f[4], f[5], f[6]};
-                memcpy(k.w, row, sizeof row);
-                auto it = dict.find(k);
-                if (it == dict.end()) {
-                    if (dict.size() >= mat_cap) { ok = false; break; }
-                    it = dict.emplace(k, (uint32_t)dict.size()).first;
-                    table.insert(table.end(), row, row + 5);
-                    table.push_back(mode == 2 ? 1.0f / row[0] : 0.0f); // 1 / length: one IEEE divide per material
-                }
-                mat_of_slot[s] = it->second;
-            }
-            if (ok) {
-                e->mat_mode = (uint32_t)mode;
-                mat_table.swap(table);
-                break;
-            }
-        }
+        SbMatDict mdict;
+        build_material_dictionary(mdict, hb, mat_cap);
+        e->mat_mode = mdict.mode;
+        mat_table.swap(mdict.table);
         if (e->mat_mode == 0) lbits = 16;
         e->lbits = lbits;
         e->nmat = (uint32_t)(mat_table.size() / 6);
-        c_pair.assign(tl.copy_la.size(), 0xFFFFFFFFu);
-        for (size_t c = 0; c < c_pair.size(); c++) {
-            if (tl.copy_slot[c] == 0xFFFFFFFFu) continue;
-            uint32_t w = tl.copy_la[c] | (tl.copy_lb[c] << lbits);
-            if (e->mat_mode) w |= mat_of_slot[tl.copy_slot[c]] << (2 * lbits);
-            c_pair[c] = w;
-        }
+        c_pair.resize(tl.copy_la.size());
+        sbt::parallel_ranges(c_pair.size(), 1 << 16, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; c++) {
+                uint32_t w = 0xFFFFFFFFu;
+                if (tl.copy_slot[c] != 0xFFFFFFFFu) {
+                    w = tl.copy_la[c] | (tl.copy_lb[c] << lbits);
+                    if (e->mat_mode) w |= mdict.of_slot[tl.copy_slot[c]] << (2 * lbits);
+                }
+                c_pair[c] = w;
+            }
+        });
         e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_all * sizeof(int2) + (size_t)e->nmat * 6 * sizeof(float);
         if (e->lds_bytes > 160 * 1024)
             SB_FAIL(e, SB_ERR_UNSUPPORTED, "tile needs %zu bytes of LDS (> 160 KiB): lower tile_particles or use SB_PATH_ATOMIC", e->lds_bytes);
@@ -636,7 +760,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         float *SbBeamArrays::*fields[9] = {&SbBeamArrays::length, &SbBeamArrays::target, &SbBeamArrays::last,
                                            &SbBeamArrays::spring, &SbBeamArrays::damp,   &SbBeamArrays::yield,
                                            &SbBeamArrays::limit,  &SbBeamArrays::strain, &SbBeamArrays::stress};
-        std::vector<float> tmp(nc);
+        sbt::uvec<float> tmp(nc);
         for (int k = 0; k < 9; k++) {
             // the material table replaces the static parameter arrays (and the length array in mode 2)
             const bool is_static = k == 0 || (k >= 3 && k <= 6);
@@ -644,23 +768,25 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
                 e->beams.*fields[k] = nullptr;
                 continue;
             }
-            for (uint32_t c = 0; c < nc; c++) tmp[c] = c_slot[c] == 0xFFFFFFFFu ? 0.0f : hb[c_slot[c]].f[k];
+            sbt::parallel_ranges(nc, 1 << 16, [&](size_t c0, size_t c1) {
+                for (size_t c = c0; c < c1; c++) tmp[c] = c_slot[c] == 0xFFFFFFFFu ? 0.0f : hb[c_slot[c]].f[k];
+            });
             SB_TRY(dev_alloc(e, &(e->beams.*fields[k]), nc));
-            if (nc) SB_HIP(e, hipMemcpy(e->beams.*fields[k], tmp.data(), nc * 4, hipMemcpyHostToDevice));
+            if (nc) SB_TRY(stage_put_bytes(e, e->beams.*fields[k], tmp.data(), (size_t)nc * 4));
         }
         SB_TRY(dev_alloc(e, &e->beams.slot, nc));
-        if (nc) SB_HIP(e, hipMemcpy(e->beams.slot, c_slot.data(), nc * 4, hipMemcpyHostToDevice));
+        if (nc) SB_TRY(stage_put_bytes(e, e->beams.slot, c_slot.data(), (size_t)nc * 4));
         if (e->path == SB_PATH_TILED) {
             SB_TRY(dev_alloc(e, &e->beams.pair, nc));
-            if (nc) SB_HIP(e, hipMemcpy(e->beams.pair, c_pair.data(), nc * 4, hipMemcpyHostToDevice));
+            if (nc) SB_TRY(stage_put_bytes(e, e->beams.pair, c_pair.data(), (size_t)nc * 4));
             SB_TRY(dev_alloc(e, &e->d_mat, mat_table.size()));
             if (!mat_table.empty())
                 SB_HIP(e, hipMemcpy(e->d_mat, mat_table.data(), mat_table.size() * 4, hipMemcpyHostToDevice));
         } else {
             SB_TRY(dev_alloc(e, &e->beams.ia, nc));
             SB_TRY(dev_alloc(e, &e->beams.ib, nc));
-            if (nc) SB_HIP(e, hipMemcpy(e->beams.ia, c_ia.data(), nc * 4, hipMemcpyHostToDevice));
-            if (nc) SB_HIP(e, hipMemcpy(e->beams.ib, c_ib.data(), nc * 4, hipMemcpyHostToDevice));
+            if (nc) SB_TRY(stage_put_bytes(e, e->beams.ia, c_ia.data(), (size_t)nc * 4));
+            if (nc) SB_TRY(stage_put_bytes(e, e->beams.ib, c_ib.data(), (size_t)nc * 4));
         }
     }
     tm.mark("beams to device");
@@ -763,6 +889,17 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     e->h_beams.swap(hb);
     e->loaded = true;
     tm.mark("masks + final sync");
+    {
+        auto *trash = new SbUploadTrash;
+        trash->px.swap(px);
+        trash->py.swap(py);
+        std::swap(trash->tl, tl);
+        std::swap(trash->bl, bl);
+        trash->hb.swap(hb); // (the previous scene's records)
+        std::vector<uint32_t> *big[8] = {&slot_index, &internal_of_index, &order, &internal_of_slot, &c_ia, &c_ib, &c_pair, &c_slot};
+        for (int k = 0; k < 8; k++) trash->v[k].swap(*big[k]);
+        e->reaper = std::thread([trash] { delete trash; });
+    }
     return SB_OK;
 }
 
@@ -859,10 +996,15 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
 }
 
 // per-slot delete generation -> host; returns the number of dead slots
-static sb_status fetch_dead(sb_engine *e, std::vector<uint32_t> &dead, uint32_t *ndead)
+static sb_status fetch_dead(sb_engine *e, sbt::uvec<uint32_t> &dead, uint32_t *ndead)
 {
-    dead.assign(e->B, 0);
-    if (e->B && e->delete_gen) SB_HIP(e, hipMemcpy(dead.data(), e->d_dead_gen, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+    *ndead = 0;
+    if (!(e->B && e->delete_gen)) { // no delete pass has run since the upload: nobody is dead (and nobody needs the array)
+        dead.clear();
+        return SB_OK;
+    }
+    dead.resize(e->B);
+    SB_TRY(stage_get_bytes(e, dead.data(), e->d_dead_gen, (size_t)e->B * 4));
     uint32_t n = 0;
     for (uint32_t g : dead) n += g != 0;
     *ndead = n;
@@ -875,7 +1017,7 @@ sb_status sb_get_counts(sb_engine *e, uint32_t *particles, uint32_t *beams)
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_get_counts before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
-    std::vector<uint32_t> dead;
+    sbt::uvec<uint32_t> dead;
     uint32_t nd = 0;
     SB_TRY(fetch_dead(e, dead, &nd));
     if (particles) *particles = e->P;
@@ -896,8 +1038,9 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
     if (beams && beams_bytes < (size_t)maxB * bstride) SB_FAIL(e, SB_ERR_INVALID, "beam buffer too small");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream)); // engineWorker.ts:554
+    SbStageTimer tm;
 
-    std::vector<uint32_t> dead;
+    sbt::uvec<uint32_t> dead;
     uint32_t nd = 0;
     SB_TRY(fetch_dead(e, dead, &nd));
 
@@ -934,12 +1077,13 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
             }
         }
     }
+    tm.mark("readback: metadata + mapping");
     if (particles && P) {
-        std::vector<float2> hp(P), hv(P), ha(P);
+        sbt::uvec<float2> hp(P), hv(P), ha(P);
         const SbParticleArrays &c = e->part[e->cur];
-        SB_HIP(e, hipMemcpy(hp.data(), c.pos, P * sizeof(float2), hipMemcpyDeviceToHost));
-        SB_HIP(e, hipMemcpy(hv.data(), c.vel, P * sizeof(float2), hipMemcpyDeviceToHost));
-        SB_HIP(e, hipMemcpy(ha.data(), c.acc, P * sizeof(float2), hipMemcpyDeviceToHost));
+        SB_TRY(stage_get_bytes(e, hp.data(), c.pos, P * sizeof(float2)));
+        SB_TRY(stage_get_bytes(e, hv.data(), c.vel, P * sizeof(float2)));
+        SB_TRY(stage_get_bytes(e, ha.data(), c.acc, P * sizeof(float2)));
         uint8_t *out = (uint8_t *)particles;
         sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
             for (size_t i = i0; i < i1; i++) {
@@ -948,13 +1092,15 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
             }
         });
     }
+    tm.mark("readback: particles");
     if (beams && B) {
         const uint32_t nc = e->nbeam;
-        std::vector<float> t(nc), l(nc), sn(nc), ss(nc);
-        SB_HIP(e, hipMemcpy(t.data(), e->beams.target, nc * 4, hipMemcpyDeviceToHost));
-        SB_HIP(e, hipMemcpy(l.data(), e->beams.last, nc * 4, hipMemcpyDeviceToHost));
-        SB_HIP(e, hipMemcpy(sn.data(), e->beams.strain, nc * 4, hipMemcpyDeviceToHost));
-        SB_HIP(e, hipMemcpy(ss.data(), e->beams.stress, nc * 4, hipMemcpyDeviceToHost));
+        sbt::uvec<float> t(nc), l(nc), sn(nc), ss(nc);
+        SB_TRY(stage_get_bytes(e, t.data(), e->beams.target, (size_t)nc * 4));
+        SB_TRY(stage_get_bytes(e, l.data(), e->beams.last, (size_t)nc * 4));
+        SB_TRY(stage_get_bytes(e, sn.data(), e->beams.strain, (size_t)nc * 4));
+        SB_TRY(stage_get_bytes(e, ss.data(), e->beams.stress, (size_t)nc * 4));
+        tm.mark("readback: beam state to host");
         uint8_t *out = (uint8_t *)beams;
         const size_t foff = e->opt.layout == SB_LAYOUT_V1 ? 4 : 8;
         sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
@@ -978,6 +1124,7 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
             memcpy(f + 32, &ss[c], 4); // stress
         }
         });
+        tm.mark("readback: beam records");
     }
     return SB_OK;
 }

@@ -35,20 +35,20 @@ struct SbBlocking {
     std::vector<uint32_t> order;     // internal particle -> slot (tiles are contiguous ranges)
     std::vector<uint32_t> tile_p0;   // [T+1] own particles
     std::vector<uint32_t> tile_h0;   // [T+1] halo ranges
-    std::vector<uint32_t> halo_idx;  // internal particle index of each halo entry (sorted by ring, then index)
-    std::vector<uint32_t> ring_cnt;  // [T][K+1] region particles with ring <= r (ring_cnt[t][0] = own)
+    sbt::uvec<uint32_t> halo_idx;  // internal particle index of each halo entry (sorted by ring, then index)
+    sbt::uvec<uint32_t> ring_cnt;  // [T][K+1] region particles with ring <= r (ring_cnt[t][0] = own)
     std::vector<uint32_t> tile_b0;   // [T+1] owned beams = ranges of the state arrays
-    std::vector<uint32_t> beam_slot; // [NB] mapping slot of state index g
-    std::vector<uint32_t> g_of_slot; // [B]
+    sbt::uvec<uint32_t> beam_slot; // [NB] mapping slot of state index g
+    sbt::uvec<uint32_t> g_of_slot; // [B]
     std::vector<uint32_t> tile_e0;   // [T+1] entry ranges
-    std::vector<uint32_t> ent_la, ent_lb, ent_slot; // region-local endpoint indices, beam slot
-    std::vector<uint32_t> lvl_cnt;   // [T][K] entries whose smaller ring is <= m (m = 0..K-1)
+    sbt::uvec<uint32_t> ent_la, ent_lb, ent_slot; // region-local endpoint indices, beam slot
+    sbt::uvec<uint32_t> lvl_cnt;   // [T][K] entries whose smaller ring is <= m (m = 0..K-1)
     std::vector<uint32_t> tile_s0;   // [T+1] ranges of ent_state (entries past the tile's own beams)
-    std::vector<uint32_t> ent_state; // state index g of each non-owned entry
-    std::vector<uint32_t> slot_e0;   // [B+1] CSR beam slot -> absolute entry indices (delete pass)
-    std::vector<uint32_t> slot_ent;
+    sbt::uvec<uint32_t> ent_state; // state index g of each non-owned entry
+    sbt::uvec<uint32_t> slot_e0;     // [B+1] CSR beam slot -> absolute entry indices (delete pass)
+    sbt::uvec<uint32_t> slot_ent;
     std::vector<uint32_t> tile_n0;   // [T+1] CSR tile -> tiles that own some of its halo particles
-    std::vector<uint32_t> tile_nb;
+    sbt::uvec<uint32_t> tile_nb;
     uint32_t max_region = 0, max_entries = 0, max_own = 0;
 };
 
@@ -73,7 +73,7 @@ inline void parallel_tiles(uint32_t n, F f)
 
 // px,py: position per particle slot; beams: per beam slot, endpoints as particle slots.
 inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const std::vector<float> &py,
-                              const std::vector<SbHostBeam> &beams, uint32_t target, uint32_t K)
+                              const SbHostBeams &beams, uint32_t target, uint32_t K)
 {
     const uint32_t P = (uint32_t)px.size(), B = (uint32_t)beams.size();
     const bool timing = getenv("SB_UPLOAD_TIMING") != nullptr;
@@ -88,16 +88,21 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     t.K = K;
     sbt::bisect(px, py, t.order, t.tile_p0, target);
     const uint32_t T = t.ntiles = (uint32_t)t.tile_p0.size() - 1;
-    std::vector<uint32_t> internal_of_slot(P), tile_of(P);
-    for (uint32_t i = 0; i < P; i++) internal_of_slot[t.order[i]] = i;
-    for (uint32_t k = 0; k < T; k++)
-        for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = k;
+    sbt::uvec<uint32_t> internal_of_slot(P), tile_of(P);
+    sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) internal_of_slot[t.order[i]] = (uint32_t)i;
+    });
+    sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++)
+            for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = (uint32_t)k;
+    });
 
     mark("bisection");
     // beam endpoints as internal indices; adjacency (particle -> incident beam slots)
     // (filled by several threads with atomic cursors: the order inside a particle's list is arbitrary, and nothing below
-    // depends on it -- frontiers and entry lists are sorted after they are collected)
-    std::vector<uint32_t> ba(B), bb(B), adj0(P + 1, 0);
+    // depends on it -- out-lists, frontiers and entry lists are sorted after they are collected)
+    sbt::uvec<uint32_t> ba(B), bb(B);
+    std::vector<uint32_t> adj0(P + 1, 0);
     sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
         for (size_t s = s0; s < s1; s++) {
             ba[s] = internal_of_slot[beams[s].a];
@@ -106,10 +111,11 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
             if (bb[s] != ba[s]) __atomic_fetch_add(&adj0[bb[s] + 1], 1u, __ATOMIC_RELAXED);
         }
     });
-    for (uint32_t i = 0; i < P; i++) adj0[i + 1] += adj0[i];
-    std::vector<uint32_t> adj(adj0[P]);
+    sbt::parallel_csr_scan(adj0);
+    sbt::uvec<uint32_t> adj(adj0[P]);
     {
-        std::vector<uint32_t> cur(adj0.begin(), adj0.end() - 1);
+        sbt::uvec<uint32_t> cur(P);
+        sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) { std::copy(adj0.begin() + i0, adj0.begin() + i1, cur.begin() + i0); });
         sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
             for (size_t s = s0; s < s1; s++) {
                 adj[__atomic_fetch_add(&cur[ba[s]], 1u, __ATOMIC_RELAXED)] = (uint32_t)s;
@@ -124,32 +130,48 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     // then the diagonals" -- so the endpoint gathers and the integer force adds of a wave fall into distinct LDS banks
     // instead of three or four lanes hitting the same particle (r02: 48 % of the LDS cycles were bank conflicts with
     // the entries in slot order).
-    std::vector<uint32_t> rank(B);
-    {
-        std::vector<uint32_t> out_cnt(P, 0);
-        for (uint32_t s = 0; s < B; s++) rank[s] = out_cnt[ba[s]]++;
-    }
-    // owned beams: tile of endpoint A
+    // Per particle (threads over particle ranges): its out-beams are the entries of its adjacency list with A == it, put
+    // in slot order in place at the front of the list; the rank of a beam is its position there.
+    sbt::uvec<uint32_t> rank(B), out_deg(P);
+    sbt::parallel_ranges(P, 1 << 14, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            uint32_t *l = adj.data() + adj0[i];
+            const uint32_t n = adj0[i + 1] - adj0[i];
+            uint32_t m = 0;
+            for (uint32_t e = 0; e < n; e++)
+                if (ba[l[e]] == i) std::swap(l[m++], l[e]);
+            std::sort(l, l + m);
+            for (uint32_t e = 0; e < m; e++) rank[l[e]] = e;
+            out_deg[i] = m;
+        }
+    });
+    // owned beams: tile of endpoint A.  Each tile collects, sorts and numbers its own (threads over tiles).
     t.tile_b0.assign(T + 1, 0);
-    for (uint32_t s = 0; s < B; s++) t.tile_b0[tile_of[ba[s]] + 1]++;
+    sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            uint32_t n = 0;
+            for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) n += out_deg[i];
+            t.tile_b0[k + 1] = n;
+        }
+    });
     for (uint32_t k = 0; k < T; k++) t.tile_b0[k + 1] += t.tile_b0[k];
-    t.beam_slot.assign(B, 0);
-    t.g_of_slot.assign(B, 0);
+    t.beam_slot.resize(B);
+    t.g_of_slot.resize(B);
     {
         // (keys travel with the elements: a comparator that looks rank[] and ba[] up by slot misses the cache on every compare)
         struct Key { uint64_t rank_a; uint32_t slot; };
-        std::vector<Key> keyed(B);
-        std::vector<uint32_t> cur(t.tile_b0.begin(), t.tile_b0.end() - 1);
-        for (uint32_t s = 0; s < B; s++) keyed[cur[tile_of[ba[s]]]++] = Key{((uint64_t)rank[s] << 32) | ba[s], s};
+        sbt::uvec<Key> keyed(B);
         sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
-            for (size_t k = k0; k < k1; k++)
+            for (size_t k = k0; k < k1; k++) {
+                uint32_t g = t.tile_b0[k];
+                for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++)
+                    for (uint32_t e = 0; e < out_deg[i]; e++) keyed[g++] = Key{((uint64_t)e << 32) | i, adj[adj0[i] + e]};
                 std::sort(keyed.begin() + t.tile_b0[k], keyed.begin() + t.tile_b0[k + 1],
                           [](const Key &x, const Key &y) { return x.rank_a != y.rank_a ? x.rank_a < y.rank_a : x.slot < y.slot; });
-        });
-        sbt::parallel_ranges(B, 1 << 16, [&](size_t g0, size_t g1) {
-            for (size_t g = g0; g < g1; g++) {
-                t.beam_slot[g] = keyed[g].slot;
-                t.g_of_slot[keyed[g].slot] = (uint32_t)g;
+                for (uint32_t q = t.tile_b0[k]; q < t.tile_b0[k + 1]; q++) {
+                    t.beam_slot[q] = keyed[q].slot;
+                    t.g_of_slot[keyed[q].slot] = q;
+                }
             }
         });
     }
@@ -267,7 +289,8 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     t.ent_slot.resize(E);
     t.ent_state.resize(t.tile_s0[T]);
     t.tile_nb.resize(t.tile_n0[T]);
-    t.slot_e0.assign(B + 1, 0);
+    t.slot_e0.resize(B + 1);
+    sbt::parallel_ranges(B + 1, 1 << 16, [&](size_t s0, size_t s1) { std::fill(t.slot_e0.begin() + s0, t.slot_e0.begin() + s1, 0u); });
     sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; k++) {
             const TileOut &o = out[k];
@@ -284,10 +307,11 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     sbt::parallel_ranges(E, 1 << 16, [&](size_t e0, size_t e1) {
         for (size_t e = e0; e < e1; e++) __atomic_fetch_add(&t.slot_e0[t.ent_slot[e] + 1], 1u, __ATOMIC_RELAXED);
     });
-    for (uint32_t s = 0; s < B; s++) t.slot_e0[s + 1] += t.slot_e0[s];
+    sbt::parallel_csr_scan(t.slot_e0);
     t.slot_ent.resize(E);
     {
-        std::vector<uint32_t> cur(t.slot_e0.begin(), t.slot_e0.end() - 1);
+        sbt::uvec<uint32_t> cur(B);
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) { std::copy(t.slot_e0.begin() + s0, t.slot_e0.begin() + s1, cur.begin() + s0); });
         sbt::parallel_ranges(E, 1 << 16, [&](size_t e0, size_t e1) {
             for (size_t e = e0; e < e1; e++) t.slot_ent[__atomic_fetch_add(&cur[t.ent_slot[e]], 1u, __ATOMIC_RELAXED)] = (uint32_t)e;
         });

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/softbody.h"
@@ -74,7 +75,7 @@ struct sb_engine {
     std::vector<uint32_t> h_pidx;    // internal particle -> data index
     std::vector<uint32_t> h_pslot;   // internal particle -> mapping slot
     std::vector<uint32_t> h_copy_of_slot; // beam slot -> index of the copy read back for it
-    std::vector<SbHostBeam> h_beams;      // static part of every active beam record, per slot
+    SbHostBeams h_beams;      // static part of every active beam record, per slot
 
     // device state
     SbParticleArrays part[2]{};
@@ -133,6 +134,13 @@ struct sb_engine {
     uint32_t *d_grid_done = nullptr;  // workgroups of the hash build in progress that have finished (zero between builds)
     uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
     uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)
+    // pinned staging of uploads and read-backs (sb_api.hip: stage_*): two chunks, filled / drained by several host threads while
+    // the other one is on the wire (hipMemcpy from pageable memory stages through ONE thread: ~5 GB/s)
+    uint8_t *stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int stage_cur = 0;
+    std::thread reaper;               // frees the host arrays of the last upload (sb_api.hip: SbUploadTrash)
 
     size_t device_bytes = 0;
     std::vector<void *> allocs;

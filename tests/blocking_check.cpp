@@ -47,7 +47,7 @@ int main(int argc, char **argv)
     const uint32_t K = atoi(argv[6]);
     const uint32_t P = w * h;
     std::vector<float> px(P), py(P);
-    std::vector<SbHostBeam> beams;
+    SbHostBeams beams;
     auto add = [&](uint32_t a, uint32_t b) { SbHostBeam s{}; s.a = a; s.b = b; beams.push_back(s); };
     for (uint32_t x = 0; x < w; x++)
         for (uint32_t y = 0; y < h; y++) {

@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     const int mode = atoi(argv[5]);
     const uint32_t P = w * h;
     std::vector<float> px(P), py(P);
-    std::vector<SbHostBeam> beams;
+    SbHostBeams beams;
     for (uint32_t x = 0; x < w; x++)
         for (uint32_t y = 0; y < h; y++) {
             uint32_t i = x * h + y;
