@@ -40,17 +40,48 @@ void sb_set_create_error(const char *msg) { g_create_error = msg ? msg : ""; } /
         }                                                                                     \
     } while (0)
 
+// Device arrays of a scene come from a per-engine pool: an upload that replaces a scene (the reference uploads after every
+// edit, engineWorker.ts:569-601) finds last scene's blocks there instead of paying ~30 hipFree + hipMalloc pairs, each a device
+// synchronisation (28 ms of a 128 ms re-upload of 1 M particles).  A block serves a request of up to its own size and at least
+// half of it; new blocks get an eighth of head-room so that a slightly larger scene still fits.
 template <typename T>
 static sb_status dev_alloc(sb_engine *e, T **p, size_t n)
 {
     *p = nullptr;
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    void *q = nullptr;
-    SB_HIP(e, hipMalloc(&q, bytes));
-    e->allocs.push_back(q);
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    size_t best = SIZE_MAX;
+    for (size_t k = 0; k < e->pool_free.size(); k++) {
+        const size_t have = e->pool_free[k].second;
+        if (have >= bytes && have / 2 <= bytes && (best == SIZE_MAX || have < e->pool_free[best].second)) best = k;
+    }
+    std::pair<void *, size_t> blk;
+    if (best != SIZE_MAX) {
+        blk = e->pool_free[best];
+        e->pool_free.erase(e->pool_free.begin() + (ptrdiff_t)best);
+    } else {
+        const size_t want = bytes + (bytes >= (1u << 20) ? bytes / 8 : 0);
+        void *q = nullptr;
+        SB_HIP(e, hipMalloc(&q, want));
+        blk = {q, want};
+    }
+    e->pool_used.push_back(blk);
     e->device_bytes += bytes;
-    *p = (T *)q;
+    *p = (T *)blk.first;
     return SB_OK;
+}
+// blocks the new scene did not take: kept while they are small change next to the scene itself, else returned
+static void pool_trim(sb_engine *e)
+{
+    size_t idle = 0;
+    for (const auto &b : e->pool_free) idle += b.second;
+    while (!e->pool_free.empty() && idle > e->device_bytes / 4) {
+        size_t big = 0;
+        for (size_t k = 1; k < e->pool_free.size(); k++)
+            if (e->pool_free[k].second > e->pool_free[big].second) big = k;
+        idle -= e->pool_free[big].second;
+        (void)hipFree(e->pool_free[big].first);
+        e->pool_free.erase(e->pool_free.begin() + (ptrdiff_t)big);
+    }
 }
 
 #define SB_TRY(x)                          \
@@ -89,8 +120,10 @@ static void reap_join(sb_engine *e)
 
 static void free_scene(sb_engine *e)
 {
-    for (void *p : e->allocs) (void)hipFree(p);
+    for (void *p : e->allocs) (void)hipFree(p); // (what does not go through the pool: the fine-grained mailbox)
     e->allocs.clear();
+    e->pool_free.insert(e->pool_free.end(), e->pool_used.begin(), e->pool_used.end());
+    e->pool_used.clear();
     e->device_bytes = 0;
     e->loaded = false;
     e->n_ghost_p = e->n_send_p = e->n_ghost_b = e->n_send_b = e->n_ghost_b_copies = 0;
@@ -476,6 +509,8 @@ sb_status sb_destroy(sb_engine *e)
     (void)hipStreamSynchronize(e->stream);
     reap_join(e);
     free_scene(e);
+    for (const auto &b : e->pool_free) (void)hipFree(b.first);
+    e->pool_free.clear();
     if (e->dev_err) (void)hipHostFree(e->dev_err);
     if (e->stage[0]) (void)hipHostFree(e->stage[0]);
     for (int k = 0; k < 2; k++)
@@ -888,6 +923,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     SB_HIP(e, hipDeviceSynchronize());
     e->h_beams.swap(hb);
     e->loaded = true;
+    pool_trim(e);
     tm.mark("masks + final sync");
     {
         auto *trash = new SbUploadTrash;
@@ -1268,10 +1304,10 @@ static sb_status sb_halo_configure_impl(sb_engine *e, const uint32_t *ghost_part
     for (void *old : {(void *)e->d_ghost_p, (void *)e->d_send_p, (void *)e->d_send_b, (void *)e->d_ghost_b, (void *)e->d_send_p_off,
                       (void *)e->d_send_b_off, (void *)e->d_ghost_p_off, (void *)e->d_ghost_b_off}) {
         if (!old) continue;
-        auto it = std::find(e->allocs.begin(), e->allocs.end(), old);
-        if (it != e->allocs.end()) {
-            (void)hipFree(old);
-            e->allocs.erase(it);
+        auto it = std::find_if(e->pool_used.begin(), e->pool_used.end(), [old](const std::pair<void *, size_t> &b) { return b.first == old; });
+        if (it != e->pool_used.end()) { // back to the pool (the lists that replace them are about to ask for the same sizes)
+            e->pool_free.push_back(*it);
+            e->pool_used.erase(it);
         }
     }
     e->d_ghost_p = e->d_send_p = e->d_send_b = e->d_send_p_off = e->d_send_b_off = e->d_ghost_p_off = e->d_ghost_b_off = nullptr;

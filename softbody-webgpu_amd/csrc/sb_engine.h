@@ -143,7 +143,8 @@ struct sb_engine {
     std::thread reaper;               // frees the host arrays of the last upload (sb_api.hip: SbUploadTrash)
 
     size_t device_bytes = 0;
-    std::vector<void *> allocs;
+    std::vector<void *> allocs;                             // freed with the scene (not pooled)
+    std::vector<std::pair<void *, size_t>> pool_used, pool_free; // device blocks of the scene / kept for the next upload (sb_api.hip dev_alloc)
 };
 
 // sb_kernels.hip
