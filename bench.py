@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--block-substeps", type=int, default=0,
                     help="collisions off: substeps per launch of the temporally blocked kernel (0 = engine default, 1 = off)")
-    ap.add_argument("--ghost-depth", type=int, default=25,
+    ap.add_argument("--ghost-depth", type=int, default=30,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
     ap.add_argument("--subticks", type=int, default=64)
     ap.add_argument("--soup", action="store_true",

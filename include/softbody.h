@@ -86,7 +86,7 @@ typedef struct sb_options {
                               * fixed; negative = rebuild every substep */
     uint32_t block_substeps; /* SB_PATH_TILED with SB_COLLIDE_OFF: substeps one launch advances out of LDS and
                               * registers (temporal blocking over beam-hop rings; same bits as single substeps).
-                              * 0 = default (5), 1 = one launch per substep, at most 8; lowered
+                              * 0 = default (6), 1 = one launch per substep, at most 8; lowered
                               * automatically until every tile's region fits the kernel's registers and LDS */
     uint32_t reserved[3];
 } sb_options;

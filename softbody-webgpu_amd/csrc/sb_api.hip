@@ -658,7 +658,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             // K substeps per launch, K as large as asked for while every tile's region still fits the kernel's
             // per-thread register arrays and 12-bit local indices
             const uint32_t region_cap = std::min<uint32_t>(SB_BK_MAXP * SB_BK_T, (1u << SB_BK_LBITS) - 2u);
-            for (blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : 5u, SB_BK_KMAX); blockK; blockK--) {
+            for (blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KDEFAULT, SB_BK_KMAX); blockK; blockK--) {
                 sb_build_blocking(bl, px, py, hb, target, blockK);
                 if (bl.max_region <= region_cap && bl.max_entries <= SB_BK_MAXB * SB_BK_T) break;
             }

@@ -151,7 +151,7 @@ export type NativeEngineOptions = Partial<WGPUSoftbodyEngineOptions> & {
     readonly tileParticles?: number
     readonly device?: number
     readonly gridSkin?: number          // spatial-hash reuse margin; 0/undefined = adaptive (0.4 r .. 1.6 r), > 0 = fixed
-    readonly blockSubsteps?: number     // collisions off: substeps per launch (0/undefined = 5, 1 = one launch per substep)
+    readonly blockSubsteps?: number     // collisions off: substeps per launch (0/undefined = 6, 1 = one launch per substep)
 };
 
 export class WGPUSoftbodyEngine {

@@ -525,23 +525,28 @@ def test_mixed_stiffness_substepped(sb, oracle):
         assert_same(got, exp, "mixed stiffness path %d" % path)
 
 
-def test_reupload_replaces_everything(sb, oracle):
+@pytest.mark.parametrize("mode", [GRID, OFF])
+def test_reupload_replaces_everything(sb, oracle, mode):
     """writeBuffers() may be called again at any time (engineWorker.ts:536: every snapshot load): the second
-    scene must run as if the engine were new -- different particle/beam counts, tiling, materials, grid."""
-    eng = sb.Engine(bounds_size=4000.0, layout=2, max_particles=4000, max_beams=12000, collision_mode=GRID, path=TILED,
+    scene must run as if the engine were new -- different particle/beam counts, tiling, materials, grid.  The device
+    blocks of the previous scene are handed to the next one from a pool, stale contents and all (collisions off: the
+    temporally blocked plan; the same scene twice in a row: every block is reused as it is)."""
+    eng = sb.Engine(bounds_size=4000.0, layout=2, max_particles=4000, max_beams=12000, collision_mode=mode, path=TILED,
                     tile_particles=256)
-    for w, h, spring in ((30, 30, 50.0), (50, 20, 20.0), (10, 10, 5.0)):
+    for w, h, spring in ((30, 30, 50.0), (50, 20, 20.0), (50, 20, 20.0), (10, 10, 5.0), (40, 30, 50.0)):
         p, b = sb.scenes.rectangle(100.0, 11.0, 30.0, w, h, spring, 300.0, 0.2, 0.5, anti_diagonal=True, layout=2)
         pv = np.zeros((p.shape[0], 6), "f4")
         pv[:, :2] = p
         pv[:, 3] = -3.0
         buf = sb.Buffers(2, 4000, 12000)
         buf.set_scene(pv, b)
-        ref = oracle.OracleEngine(4000.0, 10.0, 64, 2, GRID, threads=8)
+        ref = oracle.OracleEngine(4000.0, 10.0, 64, 2, mode, threads=8)
         eng.write_buffers(buf)
         ref.write_buffers(buf)
         eng.step(70)
         ref.step(70)
+        eng.frame()
+        ref.frame()
         assert_same(eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy()), "re-upload %dx%d" % (w, h))
     eng.destroy()
 

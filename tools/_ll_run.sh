@@ -1,1 +1,3 @@
-mkdir -p gpurun_out/ll && python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_scale.py tests/test_gpu_halo.py tests/test_gpu_hardening.py -m gpu -x -q > gpurun_out/ll/tests.txt 2>&1; tail -3 gpurun_out/ll/tests.txt; rm -f gpurun_out/ll/bench.txt; python bench.py --config3 --no-cpu-baseline --no-extra >> gpurun_out/ll/bench.txt 2>&1; python bench.py --soup --no-cpu-baseline --no-extra >> gpurun_out/ll/bench.txt 2>&1;  python bench.py --collisions grid --no-cpu-baseline --no-extra >> gpurun_out/ll/bench.txt 2>&1; python bench.py --lattice-on-floor --no-cpu-baseline --no-extra >> gpurun_out/ll/bench.txt 2>&1; grep -o '"value": [0-9.e+]*\|"ms_per_step": [0-9.]*\|blocks [0-9]*' gpurun_out/ll/bench.txt; bash tools/trace_config3.sh
+for w in 1000 1050 1060; do for k in 5 6; do
+  echo "width $w K $k: $(python bench.py --width $w --block-substeps $k --no-cpu-baseline --no-extra --steps 1680 2>&1 | grep -o '"ms_per_step": [0-9.]*\|"substeps_per_launch": [0-9]*\|"region_particles": [0-9]*\|"tiles": [0-9]*' | tr '\n' ' ')"
+done; done
