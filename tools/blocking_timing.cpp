@@ -29,6 +29,14 @@ int main(int argc, char **argv)
         sb_build_blocking(t, px, py, beams, target, K);
         fprintf(stderr, "== total %.2f ms (tiles %u, entries %zu)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
                 t.ntiles, t.ent_la.size());
+        // redundancy of the plan: beam evaluations and particle integrations per launch over K x (beams, particles)
+        double ev = 0, in = 0;
+        for (uint32_t k = 0; k < t.ntiles; k++) {
+            for (uint32_t m = 0; m < K; m++) ev += t.lvl_cnt[(size_t)k * K + m];
+            for (uint32_t r = 0; r < K; r++) in += t.ring_cnt[(size_t)k * (K + 1) + r];
+        }
+        fprintf(stderr, "   K %u: beam evaluations x%.3f, particle integrations x%.3f, largest region %u, most entries %u\n", K, ev / ((double)K * beams.size()),
+                in / ((double)K * P), t.max_region, t.max_entries);
     }
     return 0;
 }
