@@ -13,9 +13,9 @@ n=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
-           "TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-           "SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"; do
+  # (a fifth pass of five TA_* counters was refused by the hardware -- "exceeds the capabilities" -- and rocprofv3 then hung
+  # until the box's silence guard killed the call: keep passes small and names taken from $OUT/avail.txt)
   n=$((n+1))
   rocprofv3 --pmc GRBM_GUI_ACTIVE $set --kernel-trace --output-format csv -d $OUT/pmc$n -- $BENCH > $OUT/pmc$n.log 2>&1 || echo "pmc pass $n failed: $set"
 done
