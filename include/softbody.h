@@ -182,6 +182,16 @@ sb_status sb_halo_pack(sb_engine *e, void *device_dst);
 /* DEVICE buffer of (6*n_ghost_particles + 2*n_ghost_beams) floats -> current state of the ghost
  * lists, enqueued on the engine's stream. */
 sb_status sb_halo_unpack(sb_engine *e, const void *device_src);
+/* Beams that BREAK in a multi-GPU run.  A flagged beam keeps acting until the delete pass at the end of its frame
+ * (compute.wgsl:205-246, engineWorker.ts:663-664), so only that pass has to agree between ranks, and a beam must
+ * disappear from every rank that holds a copy in the same pass.  The owner decides: on an engine with a halo
+ * sb_delete_pass drops the flags the GHOST copies raised themselves (their inputs may have been invalid) and removes
+ * the rest; from then on the owner's record of a removed beam travels as "dead" in every pack (a NaN payload in
+ * last_length); unpack flags the local copies of such beams, and sb_halo_delete_ghosts removes them.  A frame on
+ * every rank is therefore:  substeps with a refresh every `depth` of them  ->  sb_delete_pass  ->  one more refresh
+ * (pack / exchange / unpack, or sb_peer_exchange)  ->  sb_halo_delete_ghosts.   halo.py Exchanger.frame() and
+ * host/halo.js PeerExchanger.frame() do exactly that. */
+sb_status sb_halo_delete_ghosts(sb_engine *e);
 /* ---- direct neighbour exchange over peer mappings (xGMI stores into the neighbour's mailbox) ----
  * The alternative to moving the packed buffers with a collective library: every exchange is three
  * launches on the engine's own stream (pack straight into the neighbours' mailboxes, signal + wait,

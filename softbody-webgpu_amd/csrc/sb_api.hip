@@ -991,6 +991,18 @@ sb_status sb_delete_pass(sb_engine *e)
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_delete_pass before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
+    sbk_launch_halo_clear_ghost_flags(e); // (an engine with a halo: ghost copies die on their owner's word, sb_halo_delete_ghosts)
+    if (e->bk.K) sbk_launch_delete_blocked(e);
+    else sbk_launch_delete(e);
+    SB_HIP(e, hipGetLastError());
+    return SB_OK;
+}
+
+sb_status sb_halo_delete_ghosts(sb_engine *e)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_halo_delete_ghosts before sb_write_buffers");
+    SB_HIP(e, hipSetDevice(e->device));
     if (e->bk.K) sbk_launch_delete_blocked(e);
     else sbk_launch_delete(e);
     SB_HIP(e, hipGetLastError());

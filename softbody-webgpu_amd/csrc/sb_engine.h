@@ -151,6 +151,7 @@ struct sb_engine {
 // sb_kernels.hip
 void sbk_launch_substep(sb_engine *e, bool write_aux);
 void sbk_launch_delete(sb_engine *e);
+void sbk_launch_halo_clear_ghost_flags(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float *src);
 void sbk_launch_peer_exchange(sb_engine *e);

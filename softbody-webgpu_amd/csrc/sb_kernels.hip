@@ -615,11 +615,22 @@ __global__ __launch_bounds__(SB_BLOCK) void k_delete(SbBeamArrays b, uint32_t nw
 // ---------------------------------------------------------------- halo exchange helpers
 
 // send lists -> packed float buffer (6 floats per particle, 2 per beam, at the configured offsets)
+// What an owner sends for one of its beams: {target_length, last_length} -- or, once its delete pass has removed the beam,
+// a last_length of SB_HALO_DEAD (a NaN payload no arithmetic produces): the ghost copies on the neighbour die on the OWNER's
+// word only, never on their own redundant evaluation, whose inputs may already have been invalid.
+#define SB_HALO_DEAD 0x7FC0DEADu
+SB_DEV float2 sb_halo_beam_record(const SbBeamArrays &b, uint32_t cpy, const uint32_t *__restrict__ dead_gen)
+{
+    if (dead_gen[b.slot[cpy]] != 0u) return make_float2(0.0f, __uint_as_float(SB_HALO_DEAD));
+    return make_float2(b.target[cpy], b.last[cpy]);
+}
+
 __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(SbParticleArrays c, SbBeamArrays b,
                                                         const uint32_t *__restrict__ plist,
                                                         const uint32_t *__restrict__ poff, uint32_t np,
                                                         const uint32_t *__restrict__ blist,
-                                                        const uint32_t *__restrict__ boff, uint32_t nb, float *dst)
+                                                        const uint32_t *__restrict__ boff, uint32_t nb, float *dst,
+                                                        const uint32_t *__restrict__ dead_gen)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (k < np) {
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(SbParticleArrays c, SbBe
         o[2] = a;
     } else if (k < np + nb) {
         uint32_t j = k - np, cpy = blist[j];
-        *(float2 *)(dst + boff[j]) = make_float2(b.target[cpy], b.last[cpy]);
+        *(float2 *)(dst + boff[j]) = sb_halo_beam_record(b, cpy, dead_gen);
     }
 }
 
@@ -641,7 +652,8 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, Sb
                                                           const uint32_t *__restrict__ poff, uint32_t np,
                                                           const uint2 *__restrict__ blist,
                                                           const uint32_t *__restrict__ boff, uint32_t nbc,
-                                                          const float *__restrict__ src)
+                                                          const float *__restrict__ src, uint32_t *broken,
+                                                          const uint32_t *__restrict__ dead_gen)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
     if (k < np) {
@@ -653,8 +665,23 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, Sb
     } else if (k < np + nbc) {
         uint2 e = blist[k - np];
         float2 tl = *(const float2 *)(src + boff[e.y]);
-        b.target[e.x] = tl.x;
-        b.last[e.x] = tl.y;
+        if (__float_as_uint(tl.y) == SB_HALO_DEAD) { // removed by its owner: flag this copy for sb_halo_delete_ghosts
+            if (dead_gen[b.slot[e.x]] == 0u) atomicOr(&broken[e.x >> 5], 1u << (e.x & 31u));
+        } else {
+            b.target[e.x] = tl.x;
+            b.last[e.x] = tl.y;
+        }
+    }
+}
+
+// Ghost copies evaluate their own break condition like everybody else, but on inputs that may be invalid near the outer edge
+// of the ghost zone: their flags are dropped before a delete pass (sb_delete_pass on an engine with a halo).
+__global__ __launch_bounds__(SB_BLOCK) void k_halo_clear_ghost_flags(const uint2 *__restrict__ blist, uint32_t nbc, uint32_t *broken)
+{
+    uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (k < nbc) {
+        const uint32_t c = blist[k].x;
+        atomicAnd(&broken[c >> 5], ~(1u << (c & 31u)));
     }
 }
 
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack_peer(SbParticleArrays c,
                                                              const uint32_t *__restrict__ poff, uint32_t np,
                                                              const uint32_t *__restrict__ blist,
                                                              const uint32_t *__restrict__ boff, uint32_t nb,
-                                                             SbPeerRoute route)
+                                                             SbPeerRoute route, const uint32_t *__restrict__ dead_gen)
 {
     // one float2 per lane, consecutive lanes -> consecutive 8-byte words of the mailbox: the stores that
     // cross xGMI are fully coalesced (a lane per 24-byte record would leave every 64-byte packet a third full)
@@ -696,7 +723,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack_peer(SbParticleArrays c,
     } else if (t < 3 * np + nb) {
         uint32_t j = t - 3 * np, cpy = blist[j];
         float2 *o = (float2 *)sb_peer_route(route, boff[j]);
-        if (o) *o = make_float2(b.target[cpy], b.last[cpy]);
+        if (o) *o = sb_halo_beam_record(b, cpy, dead_gen);
     }
 }
 
@@ -788,12 +815,18 @@ void sbk_launch_delete(sb_engine *e)
                                                                  e->d_dead_gen, ++e->delete_gen, e->path == SB_PATH_TILED);
 }
 
+void sbk_launch_halo_clear_ghost_flags(sb_engine *e)
+{
+    if (!e->n_ghost_b_copies) return;
+    k_halo_clear_ghost_flags<<<cdiv(e->n_ghost_b_copies, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->d_ghost_b, e->n_ghost_b_copies, e->d_broken);
+}
+
 void sbk_launch_halo_pack(sb_engine *e, float *dst)
 {
     uint32_t n = e->n_send_p + e->n_send_b;
     if (!n) return;
     k_halo_pack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p, e->d_send_p_off,
-                                                              e->n_send_p, e->d_send_b, e->d_send_b_off, e->n_send_b, dst);
+                                                              e->n_send_p, e->d_send_b, e->d_send_b_off, e->n_send_b, dst, e->d_dead_gen);
 }
 
 void sbk_launch_halo_unpack(sb_engine *e, const float *src)
@@ -802,7 +835,7 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
     if (!n) return;
     k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->d_ghost_p_off,
                                                                 e->n_ghost_p, e->d_ghost_b, e->d_ghost_b_off,
-                                                                e->n_ghost_b_copies, src);
+                                                                e->n_ghost_b_copies, src, e->d_broken, e->d_dead_gen);
     if (e->d_grid_ctl) { // ghosts jumped: rebin (both parities: whichever the next maintain launch reads)
         (void)hipMemsetAsync(&e->d_grid_ctl[0].force, 0x01, 4, e->stream);
         (void)hipMemsetAsync(&e->d_grid_ctl[1].force, 0x01, 4, e->stream);
@@ -837,7 +870,7 @@ void sbk_launch_peer_exchange(sb_engine *e)
     if (n)
         k_halo_pack_peer<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_send_p,
                                                                        e->d_send_p_off, e->n_send_p, e->d_send_b,
-                                                                       e->d_send_b_off, e->n_send_b, route);
+                                                                       e->d_send_b_off, e->n_send_b, route, e->d_dead_gen);
     k_peer_signal_wait<<<1, 64, 0, e->stream>>>(sig);
     const float *src = (const float *)((char *)e->mailbox + SB_MAILBOX_FLAGS_BYTES +
                                        (size_t)par * sb_mailbox_stride(e->recv_floats));

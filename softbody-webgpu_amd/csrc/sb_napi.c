@@ -17,7 +17,7 @@
  *   loadBuffers(h, metadata, mapping, particles, beams)      ArrayBuffers, engineWorker.ts:548-579
  *   writeUserInput(h, bytes32)        ArrayBuffer/TypedArray, engineMapping.ts:323-325
  *   setPhysicsConstants(h, Float32Array(8)) / getPhysicsConstants(h) -> Float32Array(8)
- *   frame(h) / step(h, n) / deletePass(h) / sync(h) / stepTimed(h, n) -> ms
+ *   frame(h) / step(h, n) / deletePass(h) / haloDeleteGhosts(h) / sync(h) / stepTimed(h, n) -> ms
  *   getCounts(h) -> {particles, beams} / getInfo(h, key) -> number
  * multi-GPU (include/softbody.h "multi-GPU halo exchange", "direct neighbour exchange", "generic x-slab partition"):
  *   haloConfigure(h, ghostP, sendP, ghostB, sendB) / haloSetLayout(h, sendPOff, sendBOff, ghostPOff, ghostBOff)   Uint32Arrays
@@ -55,6 +55,7 @@ static struct {
     sb_status (*frame)(sb_engine *);
     sb_status (*step)(sb_engine *, uint32_t);
     sb_status (*delete_pass)(sb_engine *);
+    sb_status (*halo_delete_ghosts)(sb_engine *);
     sb_status (*sync)(sb_engine *);
     sb_status (*step_timed)(sb_engine *, uint32_t, float *);
     sb_status (*get_counts)(sb_engine *, uint32_t *, uint32_t *);
@@ -148,6 +149,7 @@ static napi_value js_load(napi_env env, napi_callback_info info)
     SYM(frame, "sb_frame");
     SYM(step, "sb_step");
     SYM(delete_pass, "sb_delete_pass");
+    SYM(halo_delete_ghosts, "sb_halo_delete_ghosts");
     SYM(sync, "sb_sync");
     SYM(step_timed, "sb_step_timed");
     SYM(get_counts, "sb_get_counts");
@@ -380,7 +382,7 @@ static napi_value js_simple(napi_env env, napi_callback_info info, int which, co
     CHECK_NAPI(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     sb_engine *e = argc >= 1 ? get_engine(env, argv[0]) : NULL;
     if (!e) return NULL;
-    simple_fn f = which == 0 ? sb.frame : which == 1 ? sb.delete_pass : which == 2 ? sb.sync : which == 4 ? sb.peer_exchange : sb.destroy;
+    simple_fn f = which == 0 ? sb.frame : which == 1 ? sb.delete_pass : which == 2 ? sb.sync : which == 4 ? sb.peer_exchange : which == 5 ? sb.halo_delete_ghosts : sb.destroy;
     if (which == 3) get_box(env, argv[0])->e = NULL; /* whatever sb_destroy says, the pointer is gone */
     sb_status st = f(e);
     if (st != SB_OK) return throw_status(env, which == 3 ? NULL : e, st, name);
@@ -391,6 +393,7 @@ static napi_value js_delete_pass(napi_env env, napi_callback_info info) { return
 static napi_value js_sync(napi_env env, napi_callback_info info) { return js_simple(env, info, 2, "sb_sync"); }
 static napi_value js_destroy(napi_env env, napi_callback_info info) { return js_simple(env, info, 3, "sb_destroy"); }
 static napi_value js_peer_exchange(napi_env env, napi_callback_info info) { return js_simple(env, info, 4, "sb_peer_exchange"); }
+static napi_value js_halo_delete_ghosts(napi_env env, napi_callback_info info) { return js_simple(env, info, 5, "sb_halo_delete_ghosts"); }
 
 static napi_value js_step(napi_env env, napi_callback_info info, int timed)
 {
@@ -829,7 +832,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"getCounts", js_get_counts}, {"getInfo", js_get_info},
         {"haloConfigure", js_halo_configure}, {"haloSetLayout", js_halo_set_layout}, {"haloPack", js_halo_pack},
         {"haloUnpack", js_halo_unpack}, {"getStream", js_get_stream}, {"peerMailbox", js_peer_mailbox}, {"peerMap", js_peer_map},
-        {"peerConnect", js_peer_connect}, {"peerExchange", js_peer_exchange},
+        {"peerConnect", js_peer_connect}, {"peerExchange", js_peer_exchange}, {"haloDeleteGhosts", js_halo_delete_ghosts},
         {"partitionCreate", js_partition_create}, {"partitionDestroy", js_partition_destroy},
         {"partitionRankCounts", js_partition_rank_counts}, {"partitionRankScene", js_partition_rank_scene},
         {"partitionRankIds", js_partition_rank_ids}, {"partitionPeer", js_partition_peer},

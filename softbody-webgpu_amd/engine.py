@@ -84,6 +84,7 @@ def load_library():
     L.sb_frame.argtypes = [vp]
     L.sb_step.argtypes = [vp, u32]
     L.sb_delete_pass.argtypes = [vp]
+    L.sb_halo_delete_ghosts.argtypes = [vp]
     L.sb_sync.argtypes = [vp]
     L.sb_step_timed.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_float)]
     L.sb_get_counts.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
@@ -192,6 +193,9 @@ class Engine:
 
     def delete_pass(self):
         self._check(load_library().sb_delete_pass(self._h))
+
+    def halo_delete_ghosts(self):
+        self._check(load_library().sb_halo_delete_ghosts(self._h))
 
     def sync(self):
         self._check(load_library().sb_sync(self._h))

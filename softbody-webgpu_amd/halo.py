@@ -201,7 +201,7 @@ class Exchanger:
     def __init__(self, engine, plan, transport):
         self.engine, self.plan, self.transport = engine, plan, transport
         self.since = 0
-        self.beams_at_start = engine.counts()[1]
+        self.beams_after_frames = engine.counts()[1]
         gp, sp, gb, sb_ = plan.lists()
         engine.halo_configure(gp, sp, gb, sb_)
         self.segs, n_send, n_recv, offsets = plan.segments()
@@ -209,20 +209,30 @@ class Exchanger:
         self.send, self.recv = transport.allocate(n_send, n_recv)
 
     def verify(self):
-        """Limits of the redundant ghost zones, enforced (call after stepping; it drains the engine's stream): a beam
-        that breaks is reconciled between ranks only through its two endpoints' state, not through its break flag -- a
-        ghost copy whose break is not reproduced bit for bit on the owner (its inputs were already invalid) would
-        diverge silently, and no delete pass runs across ranks.  So a halo run in which ANY beam of this rank has been
-        flagged or removed is refused.  Keep strain_break_limit out of reach in multi-GPU scenes (bench.py does).
+        """What a halo run must not have done (call after stepping; it drains the engine's stream): removed beams by any
+        other route than frame() below.  A beam that breaks keeps acting until the delete pass at the end of its frame
+        (compute.wgsl:205-246), so flagged beams are harmless between passes, and frame() makes the pass agree between ranks
+        (the owner decides, its neighbours' ghost copies follow: include/softbody.h, sb_halo_delete_ghosts).  A plain
+        engine.delete_pass() / engine.frame() on one rank is what would make the ranks diverge, silently.
         Also stated, not checkable here: a contact between particles of two NON-adjacent slabs of a folded body is
         missed (each rank only knows its neighbours' ghost zones)."""
         _, beams = self.engine.counts()
-        if beams != self.beams_at_start:
-            raise RuntimeError("halo run with broken beams (%d of %d left on rank %d): break flags are not exchanged between "
-                               "ranks; keep strain_break_limit out of reach" % (beams, self.beams_at_start, self.plan.rank))
-        if self.engine.info("beams_flagged"):
-            raise RuntimeError("halo run with beams flagged for deletion on rank %d: break flags are not exchanged between "
-                               "ranks; keep strain_break_limit out of reach" % self.plan.rank)
+        if beams != self.beams_after_frames:
+            raise RuntimeError("halo run in which rank %d lost %d beams outside Exchanger.frame(): delete passes must go "
+                               "through frame() on every rank" % (self.plan.rank, self.beams_after_frames - beams))
+
+    def frame(self):
+        """One frame on this rank: engine.subticks substeps with the usual refreshes, the delete pass of owned beams, one
+        more refresh that carries the deaths, the removal of the ghost copies.  Every rank calls it at the same time."""
+        self.step(self.engine.subticks)
+        if not self.plan.peers:
+            self.engine.delete_pass()
+        else:
+            self.engine.delete_pass()
+            self.exchange()
+            self.since = 0
+            self.engine.halo_delete_ghosts()
+        self.beams_after_frames = self.engine.counts()[1]
 
     def exchange(self):
         if not self.plan.peers:
@@ -260,7 +270,7 @@ class PeerExchanger(Exchanger):
         self.engine, self.plan, self.transport = engine, plan, None
         self.since = 0
         self.timeout_ms = timeout_ms
-        self.beams_at_start = engine.counts()[1]
+        self.beams_after_frames = engine.counts()[1]
         gp, sp, gb, sb_ = plan.lists()
         engine.halo_configure(gp, sp, gb, sb_)
         self.segs, n_send, n_recv, offsets = plan.segments()

@@ -109,7 +109,7 @@ class PeerExchanger {
         this.timeoutMs = timeoutMs || 10000;
         this.since = 0;
         this.connected = false;
-        this.beamsAtStart = this.addon.getCounts(handle).beams;
+        this.beamsAfterFrames = this.addon.getCounts(handle).beams;
         this.addon.haloConfigure(handle, ...plan.lists());
         const lay = plan.segments();
         this.segs = lay.segments;
@@ -161,12 +161,28 @@ class PeerExchanger {
         }
     }
 
-    /** break flags do not cross ranks (DESIGN.md 5): a halo run in which a beam of this rank broke is refused */
+    /**
+     * One frame on this rank (every rank calls it at the same time): `subticks` substeps with the usual refreshes, the
+     * delete pass of the beams this rank OWNS, one more refresh that carries the deaths, removal of the ghost copies
+     * (include/softbody.h, sb_halo_delete_ghosts; halo.py Exchanger.frame).  subticks: what the engine was created with.
+     */
+    frame(subticks) {
+        this.step(subticks);
+        this.addon.deletePass(this.handle);
+        if (this.plan.peers.length) {
+            this.exchange();
+            this.since = 0;
+            this.addon.haloDeleteGhosts(this.handle);
+        }
+        this.beamsAfterFrames = this.addon.getCounts(this.handle).beams;
+    }
+
+    /** beams may only disappear through frame() above: a plain deletePass()/frame() of one rank's engine makes the ranks diverge */
     verify() {
         this.addon.sync(this.handle);
         const left = this.addon.getCounts(this.handle).beams;
-        if (left !== this.beamsAtStart || this.addon.getInfo(this.handle, 'beams_flagged') !== 0)
-            throw new Error('halo run with broken beams on rank ' + this.plan.rank + ': break flags are not exchanged between ranks; keep strain_break_limit out of reach');
+        if (left !== this.beamsAfterFrames)
+            throw new Error('halo run in which rank ' + this.plan.rank + ' lost ' + (this.beamsAfterFrames - left) + ' beams outside PeerExchanger.frame()');
     }
 }
 

@@ -239,5 +239,7 @@ export class PeerExchanger {
     connect(cardsByRank: (PeerCard | undefined)[]): void;
     exchange(): void;
     step(nSubsteps: number): void;
+    /** one frame with the delete pass agreed between ranks (owner decides, ghost copies follow); every rank calls it */
+    frame(subticks: number): void;
     verify(): void;
 }

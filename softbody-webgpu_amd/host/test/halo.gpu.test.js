@@ -8,10 +8,13 @@ const { fork } = require('child_process');
 const h = require('..');
 
 const BOUNDS = 4000, DEPTH = 4, STEPS = 96, WORLD = 2;
+// HALO_FRAMES=n: beams break (strain limit 0.02) and every rank runs n whole frames with PeerExchanger.frame() -- the delete pass
+// agreed between ranks (the owner decides, the ghost copies follow); the single engine steps n frames
+const FRAMES = Number(process.env.HALO_FRAMES || 0), SUBTICKS = 64;
 
 function buildScene() {
     const m = new h.BufferMapper(1 << 27, { layout: 2, maxParticles: 2048, maxBeams: 8192 });
-    h.addRectangle(m, { particleId: 0, beamId: 0 }, 100, 40, 25, 48, 30, 50, 700, 0.2, 1e9, false);
+    h.addRectangle(m, { particleId: 0, beamId: 0 }, 100, 40, 25, 48, 30, 50, 700, 0.2, FRAMES ? 0.02 : 1e9, false);
     m.writeState();
     const f = new Float32Array(m.particleData);
     for (let i = 0; i < m.meta.particleCount; i++) { // a thrown lattice: the floor response and border accelerations act
@@ -41,14 +44,16 @@ async function child(rank) {
         process.send({ type: 'card', rank, card: ex.card });
     });
     ex.connect(cards);
-    ex.step(STEPS);
+    if (FRAMES) for (let k = 0; k < FRAMES; k++) ex.frame(SUBTICKS);
+    else ex.step(STEPS);
     ex.verify();
+    const beamsLeft = w.addon.getCounts(w.handle).beams;
     await w.loadBuffers();
     const f = new Uint32Array(bm.particleData);
     const owned = Array.from(local.plan.ownedParticles).map((i) => [local.plan.globalParticleId[i], Array.from(f.subarray(6 * i, 6 * i + 6))]);
     const substepsPerLaunch = w.addon.getInfo(w.handle, 'substeps_per_launch');
     await w.destroy();
-    process.send({ type: 'result', rank, owned, nLocal: local.plan.nLocal, ghosts: local.plan.nLocal - local.plan.nOwned, substepsPerLaunch });
+    process.send({ type: 'result', rank, owned, nLocal: local.plan.nLocal, ghosts: local.plan.nLocal - local.plan.nOwned, substepsPerLaunch, beamsLeft });
     process.disconnect();
 }
 
@@ -78,7 +83,9 @@ async function parent() {
     copyInto(w.bufferMapper.particleData, m.particleData);
     copyInto(w.bufferMapper.beamData, m.beamData);
     await w.writeBuffers();
-    await w.step(STEPS);
+    if (FRAMES) for (let k = 0; k < FRAMES; k++) { w.addon.step(w.handle, SUBTICKS); w.addon.deletePass(w.handle); }
+    else await w.step(STEPS);
+    const beamsAtStart = m.meta.beamCount, beamsLeft = w.addon.getCounts(w.handle).beams;
     await w.loadBuffers();
     const want = new Uint32Array(w.bufferMapper.particleData);
     const before = new Uint32Array(m.particleData);
@@ -98,7 +105,8 @@ async function parent() {
     }
     assert.strictEqual(compared, 48 * 30);
     assert.ok(moved > 1000);
-    console.log(JSON.stringify({ ok: true, ranks: WORLD, particles: compared, exchanges: STEPS / DEPTH,
+    if (FRAMES) assert.ok(beamsLeft < beamsAtStart - 100, 'the scene is meant to break beams: ' + beamsLeft + ' of ' + beamsAtStart);
+    console.log(JSON.stringify({ ok: true, ranks: WORLD, particles: compared, exchanges: STEPS / DEPTH, frames: FRAMES, beamsAtStart, beamsLeft,
         ghosts: results.map((r) => r.ghosts), substepsPerLaunch: results[0].substepsPerLaunch }));
 }
 

@@ -11,8 +11,41 @@ class OracleRank:
         self.ref = oracle.OracleEngine(bounds, 10.0, 64, buf.layout, mode, threads=threads)
         self.ref.write_buffers(buf)
 
+        self.subticks = self.ref.subticks
+
     def step(self, n):
         self.ref.step(n)
+
+    # ---- beams that break (include/softbody.h, sb_halo_delete_ghosts): the same protocol on the oracle's buffers.
+    # The oracle compacts the beam slots in place, so a beam is found through the live part of the mapping.
+    DEAD = np.uint32(0x7FC0DEAD)
+
+    def _beam_slots(self):
+        """data index -> current mapping slot of every live beam"""
+        md = self.ref.metadata.view("<u4")
+        live = self.ref.mapping[self.ref.max_particles:self.ref.max_particles + int(md[6])].astype(np.int64)
+        slot_of = np.full(self.ref.max_beams, -1, np.int64)
+        slot_of[live] = np.arange(live.size)
+        return slot_of
+
+    def _set_flags(self, data_idx, on):
+        slot_of = self._beam_slots()
+        for s in slot_of[np.asarray(data_idx, np.int64)]:
+            if s < 0:
+                continue
+            bit = self.ref.max_particles + int(s)
+            if on:
+                self.ref.delete[bit // 32] |= np.uint32(1 << (bit % 32))
+            else:
+                self.ref.delete[bit // 32] &= np.uint32(~(1 << (bit % 32)) & 0xFFFFFFFF)
+
+    def delete_pass(self):
+        if getattr(self, "gb", None) is not None and self.gb.size:
+            self._set_flags(self.gb, False)       # ghost copies do not decide for themselves
+        self.ref.delete_pass()
+
+    def halo_delete_ghosts(self):
+        self.ref.delete_pass()
 
     def counts(self):
         md = self.ref.metadata.view("<u4")
@@ -40,16 +73,21 @@ class OracleRank:
             dst[self.sp_off[:, None] + np.arange(6)] = self._cur()[self.sp]
         b = self.ref.beams
         if self.sb.size:
-            dst[self.sb_off] = b["target_length"][self.sb]
-            dst[self.sb_off + 1] = b["last_length"][self.sb]
+            dead = self._beam_slots()[self.sb] < 0
+            dst[self.sb_off] = np.where(dead, np.float32(0.0), b["target_length"][self.sb])
+            dst.view("<u4")[self.sb_off + 1] = np.where(dead, OracleRank.DEAD, b["last_length"][self.sb].view("<u4"))
 
     def halo_unpack(self, src):
         src = np.asarray(src)
         if self.gp.size:
             self._cur()[self.gp] = src[self.gp_off[:, None] + np.arange(6)]
         if self.gb.size:
-            self.ref.beams["target_length"][self.gb] = src[self.gb_off]
-            self.ref.beams["last_length"][self.gb] = src[self.gb_off + 1]
+            dead = src.view("<u4")[self.gb_off + 1] == OracleRank.DEAD
+            keep = ~dead
+            self.ref.beams["target_length"][self.gb[keep]] = src[self.gb_off[keep]]
+            self.ref.beams["last_length"][self.gb[keep]] = src[self.gb_off[keep] + 1]
+            if dead.any():
+                self._set_flags(self.gb[dead], True)   # (already removed copies have no slot any more: skipped)
 
     # ---- sb_peer_* double: mailboxes are numpy arrays in a registry keyed by a fake pointer; the exchange is
     # split in two (post / collect) because simulated ranks run one after another, not concurrently
@@ -162,6 +200,26 @@ def step_all(exchangers, bus, n, copy, sync=lambda: None):
             for ex in exchangers:
                 ex.engine.halo_unpack(ex.transport.pointer(ex.recv))
             since = 0
+
+
+def frame_all(exchangers, bus, copy, sync=lambda: None):
+    """Exchanger.frame() for simulated ranks in lock step: the substeps of a frame, every rank's delete pass of its OWN beams,
+    a refresh that carries the deaths, the removal of the ghost copies."""
+    step_all(exchangers, bus, exchangers[0].engine.subticks, copy, sync)
+    for ex in exchangers:
+        ex.engine.delete_pass()
+    if exchangers[0].plan.depth > 0 and any(ex.plan.peers for ex in exchangers):
+        for ex in exchangers:
+            ex.engine.halo_pack(ex.transport.pointer(ex.send))
+            ex.transport.exchange(ex.send, ex.recv, ex.segs, ex.engine)
+        sync()
+        bus.flush(copy)
+        sync()
+        for ex in exchangers:
+            ex.engine.halo_unpack(ex.transport.pointer(ex.recv))
+            ex.engine.halo_delete_ghosts()
+    for ex in exchangers:
+        ex.beams_after_frames = ex.engine.counts()[1]
 
 
 def step_all_peer(exchangers, n):

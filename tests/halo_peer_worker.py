@@ -21,7 +21,8 @@ def main():
     sb = ge.load_package()
     halo = sb.halo
     W, H, depth, steps = 40, 48, 4, 100
-    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.5)
+    frames = int(os.environ.get("HALO_FRAMES", "0"))     # > 0: beams break, whole frames with delete passes (PeerExchanger.frame)
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.02 if frames else 0.5)
 
     def engine_for(buf):
         e = sb.Engine(bounds_size=8000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
@@ -37,33 +38,52 @@ def main():
     assert len({c["pid"] for c in cards}) == world
     ex.connect(cards)
     dist.barrier()
-    ex.step(steps)
+    if frames:
+        for _ in range(frames):
+            ex.frame()
+        ex.verify()
+    else:
+        ex.step(steps)
     eng.sync()
     out = eng.load_buffers(buf.copy())
     gid, prt, bkey, brec = halo.gather_owned(plan, out)
+    live = out.mapping[out.max_particles:out.max_particles + out.beam_count].astype(np.int64)
+    own = np.zeros(out.max_beams, bool)
+    own[plan.owned_beams] = True
+    live = [int(k) for k in plan.global_beam_key[live[own[live]]]]
     gathered = [None] * world
-    dist.all_gather_object(gathered, (gid, prt, bkey, brec.tobytes()))
+    dist.all_gather_object(gathered, (gid, prt, bkey, brec.tobytes(), live))
     dist.barrier()          # nobody unmaps a mailbox a neighbour may still be writing
     eng.destroy()
     if rank == 0:
         gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
         ref = engine_for(gbuf)
-        ref.step(steps)
+        if frames:
+            for _ in range(frames):
+                ref.frame()
+        else:
+            ref.step(steps)
         want = ref.load_buffers(gbuf.copy())
         ref.destroy()
         parts = np.zeros_like(want.particles)
-        for g, p, _, _ in gathered:
+        alive = set()
+        for g, p, _, _, lk in gathered:
             parts[g] = p
+            alive |= set(lk)
+        if frames:
+            assert want.beam_count < gbuf.beam_count - 10, "the scene is meant to break beams"
+            gl = want.mapping[want.max_particles:want.max_particles + want.beam_count].astype(np.int64)
+            assert alive == set(int(k) for k in gplan.global_beam_key[gl]), "different beams removed"
         assert np.array_equal(parts.view("u4"), want.particles.view("u4")), "particles differ"
         wantb = {int(k): r.tobytes()[8:] for k, r in zip(gplan.global_beam_key, want.beams)}
         n = 0
-        for _, _, bk, bb in gathered:
+        for _, _, bk, bb, _ in gathered:
             recs = np.frombuffer(bb, dtype=want.beams.dtype)
             for k, r in zip(bk, recs):
                 assert wantb[int(k)] == r.tobytes()[8:], "beam differs"
                 n += 1
         assert n == len(wantb)
-        print("HALO_PEER_OK ranks=%d particles=%d beams=%d" % (world, parts.shape[0], n), flush=True)
+        print("HALO_PEER_OK ranks=%d particles=%d beams=%d frames=%d beams left %d" % (world, parts.shape[0], n, frames, want.beam_count), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -65,6 +65,78 @@ def test_simulated_gpu_ranks_equal_single_engine(sb, world, depth, path):
     assert (want.particles[:, 1] == 10.0).any()
 
 
+@pytest.mark.parametrize("world,depth,path,block", [(2, 4, 2, 0), (3, 6, 2, 0), (2, 5, 2, 1), (2, 3, 1, 0)])
+def test_beams_that_break_across_simulated_gpu_ranks(sb, world, depth, path, block):
+    """Frames with delete passes across ranks on the real kernels (blocked plan, single-substep tiling, atomic path): the
+    owner's delete pass, the refresh that carries the deaths (a NaN payload in last_length), sb_halo_delete_ghosts on the
+    neighbours.  Same particles, same owner records and the same beams gone as the single engine stepping whole frames."""
+    import torch
+    from halo_oracle import LocalBus, frame_all
+    halo = sb.halo
+    W, H, frames = 40, 48, 3
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.02)
+    bounds = 8000.0
+
+    def engine_for(buf):
+        e = sb.Engine(bounds_size=bounds, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                      collision_mode=0, path=path, tile_particles=256, block_substeps=block)
+        e.write_buffers(buf)
+        return e
+
+    def live_keys(plan, out, owned_only=True):
+        live = out.mapping[out.max_particles:out.max_particles + out.beam_count].astype(np.int64)
+        if owned_only:
+            own = np.zeros(out.max_beams, bool)
+            own[plan.owned_beams] = True
+            live = live[own[live]]
+        return set(int(k) for k in plan.global_beam_key[live])
+
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    ref = engine_for(gbuf)
+    for _ in range(frames):
+        ref.frame()
+    want = ref.load_buffers(gbuf.copy())
+    ref.destroy()
+    assert want.beam_count < gbuf.beam_count - 100, "the scene is meant to break beams"
+
+    dev = torch.device("cuda", 0)
+    bus = LocalBus()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng = engine_for(buf)
+        tr = bus.transport(r, lambda a, b: (torch.zeros(max(a, 1), device=dev), torch.zeros(max(b, 1), device=dev)),
+                           lambda t: t.data_ptr())
+        exs.append(halo.Exchanger(eng, plan, tr))
+        made.append((buf, plan, eng))
+
+    def sync():
+        for _, _, e in made:
+            e.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(frames):
+        frame_all(exs, bus, lambda dst, src: dst.copy_(src), sync)
+    for ex in exs:
+        ex.verify()
+    parts = np.zeros_like(want.particles)
+    beams, live = {}, set()
+    for buf, plan, eng in made:
+        out = eng.load_buffers(buf.copy())
+        gid, prt, bkey, brec = halo.gather_owned(plan, out)
+        parts[gid] = prt
+        for k, rec in zip(bkey, brec):
+            beams[int(k)] = rec.tobytes()[8:]
+        live |= live_keys(plan, out)
+        # ghost copies: none outlives its owner's beam, none died on its own (stale inputs at the edge of the zone)
+        assert live_keys(plan, out, owned_only=False) == set(int(k) for k in plan.global_beam_key) & live_keys(gplan, want)
+        eng.destroy()
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    assert live == live_keys(gplan, want)
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)] == rec.tobytes()[8:]
+
+
 @pytest.mark.parametrize("world,depth", [(2, 4), (3, 8)])
 def test_peer_exchange_in_process_equals_single_engine(sb, world, depth):
     """sb_peer_* between engines of one process (each on its own stream, mailboxes passed by pointer):
@@ -194,13 +266,15 @@ def test_peer_wait_gives_up_instead_of_hanging(sb):
         ex.engine.destroy()
 
 
-def test_two_processes_peer_exchange(sb):
-    """IPC-mapped mailboxes between two OS processes on this GPU (tests/halo_peer_worker.py)."""
+@pytest.mark.parametrize("frames", [0, 3])
+def test_two_processes_peer_exchange(sb, frames):
+    """IPC-mapped mailboxes between two OS processes on this GPU (tests/halo_peer_worker.py).  frames > 0: beams break and
+    both processes run PeerExchanger.frame() -- delete pass, a refresh that carries the deaths, removal of the ghost copies."""
     import subprocess
-    port = 29500 + os.getpid() % 2000
+    port = 29500 + (os.getpid() + 7 * frames) % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "halo_peer_worker.py")]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, HALO_FRAMES=str(frames)))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "HALO_PEER_OK" in p.stdout
 

@@ -89,8 +89,10 @@ def test_reconnecting_a_used_mailbox_is_refused(sb):
         e.destroy()
 
 
-def test_halo_run_with_broken_beams_is_refused(sb):
-    """Break flags are not exchanged between ranks: a halo run in which a beam broke must say so."""
+def test_halo_run_refuses_a_delete_pass_that_bypasses_the_exchanger(sb):
+    """Beams that break in a halo run are removed through Exchanger.frame() (owner decides, ghost copies follow).  Flagged
+    beams by themselves are harmless -- they act until the next delete pass -- but a delete pass run on one engine behind
+    the exchanger's back makes the ranks diverge, and verify() must say so."""
     made = slabs(sb, 2, strain_limit=0.02, velocity=(-60.0, -50.0))
     exs = [sb.halo.PeerExchanger(e, plan, timeout_ms=2000) for _, plan, e in made]
     cards = [ex.card for ex in exs]
@@ -99,7 +101,11 @@ def test_halo_run_with_broken_beams_is_refused(sb):
     for _ in range(40):
         for ex in exs:
             ex.step(4)
-    with pytest.raises(RuntimeError, match="break flags are not exchanged"):
+    assert sum(e.info("beams_flagged") for _, _, e in made) > 0, "the scene is meant to break beams"
+    for ex in exs:
+        ex.verify()                      # flagged, not yet removed: fine
+    made[0][2].delete_pass()             # ... one rank deletes on its own
+    with pytest.raises(RuntimeError, match="outside Exchanger.frame"):
         for ex in exs:
             ex.verify()
     for _, _, e in made:

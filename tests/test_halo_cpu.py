@@ -86,6 +86,63 @@ def test_simulated_ranks_equal_single_run(sb, oracle, world, depth, steps):
     assert (want.particles[:, 1] == 10.0).any()  # the lattice reached the floor
 
 
+def live_beam_keys(plan, buf, owned_only=True):
+    """global keys of the beams still in the mapping (engineMapping.ts: the first beam_count beam slots)"""
+    live = buf.mapping[buf.max_particles:buf.max_particles + buf.beam_count].astype(np.int64)
+    if owned_only:
+        own = np.zeros(buf.max_beams, bool)
+        own[plan.owned_beams] = True
+        live = live[own[live]]
+    return set(int(k) for k in plan.global_beam_key[live])
+
+
+@pytest.mark.parametrize("world,depth,limit,velocity", [(2, 4, 0.05, (0.3, -4.0)), (3, 3, 0.02, (0.3, -4.0)), (3, 5, 0.02, (6.0, -8.0))])
+def test_beams_that_break_are_deleted_on_every_rank_in_the_same_pass(sb, oracle, world, depth, limit, velocity):
+    """Frames with delete passes across ranks (include/softbody.h, sb_halo_delete_ghosts): the owner removes its broken
+    beams, the refresh right after carries the deaths, the neighbours' ghost copies follow -- the merged state equals the
+    single-engine run bit for bit, with the same beams gone, while ghost copies near the outer edge of a zone (whose inputs
+    are stale) flag themselves spuriously or not at all."""
+    from halo_oracle import LocalBus, OracleRank, frame_all
+    halo = sb.halo
+    W, H, frames = 6, 7, 3
+    kw = dict(d=25.0, origin=(100.0, 11.5), jitter=1.0, velocity=velocity, strain_limit=limit)
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    ref = OracleRank(oracle, gbuf, 1000.0)
+    for _ in range(frames):
+        ref.ref.frame()
+    want = ref.load(gbuf)
+    assert want.beam_count < gbuf.beam_count - 10, "the scene is meant to break beams"
+    bus = LocalBus()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng = OracleRank(oracle, buf, 1000.0)
+        tr = bus.transport(r, lambda a, b: (np.zeros(max(a, 1), "f4"), np.zeros(max(b, 1), "f4")), lambda t: t)
+        exs.append(halo.Exchanger(eng, plan, tr))
+        made.append((buf, plan, eng))
+
+    def copy(dst, src):
+        dst[:] = src
+
+    for _ in range(frames):
+        frame_all(exs, bus, copy)
+    for ex in exs:
+        ex.verify()
+    loaded = [(plan, eng.load(buf)) for buf, plan, eng in made]
+    parts, beams = merged_state(loaded, W * world * H, None)
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    live = set()
+    for plan, buf in loaded:
+        live |= live_beam_keys(plan, buf)
+    assert live == live_beam_keys(gplan, want)
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)].tobytes()[8:] == rec.tobytes()[8:], "beam %d" % k   # (the OWNER's record, removed beams included)
+    # and every rank agrees with the owners about its ghost copies too: none outlives its owner's beam, none died on its own
+    for plan, buf in loaded:
+        here = set(int(k) for k in plan.global_beam_key)      # every beam this rank holds, owned or ghost
+        assert live_beam_keys(plan, buf, owned_only=False) == here & live
+
+
 @pytest.mark.parametrize("world,depth", [(2, 3), (4, 2)])
 def test_peer_exchanger_routing_equals_single_engine(sb, oracle, world, depth):
     """PeerExchanger's wiring (whose mailbox, which flag slot, which destination offset) on oracle-backed
@@ -166,12 +223,13 @@ def test_without_refresh_ghost_zone_goes_stale(sb, oracle):
     assert not np.array_equal(got.particles[plan.owned_particles], want.particles[gid])
 
 
-def test_gloo_world_size_2(sb, oracle):
+@pytest.mark.parametrize("frames", [0, 3])
+def test_gloo_world_size_2(sb, oracle, frames):
     """Real torch.distributed ranks (gloo, 127.0.0.1), the same Exchanger/TorchTransport the GPU bench
-    uses, oracle-backed engines on CPU tensors."""
-    port = 29500 + os.getpid() % 2000
+    uses, oracle-backed engines on CPU tensors.  frames > 0: beams break and every rank runs Exchanger.frame()."""
+    port = 29500 + (os.getpid() + 7 * frames) % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "halo_gloo_worker.py")]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HALO_FRAMES=str(frames)))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "HALO_GLOO_OK" in p.stdout

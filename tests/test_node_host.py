@@ -62,3 +62,6 @@ def test_js_two_processes_trade_ghost_zones():
     trading ghost zones through IPC-mapped mailboxes on one GPU; together bit-identical to the single engine."""
     r = run_node("halo.gpu.test.js", timeout=600)
     assert r["ok"] and r["particles"] == 1440 and r["exchanges"] == 24 and min(r["ghosts"]) > 0
+    # and with beams that break: whole frames through PeerExchanger.frame(), the delete pass agreed between the processes
+    r = run_node("halo.gpu.test.js", env={"HALO_FRAMES": "3"}, timeout=600)
+    assert r["ok"] and r["particles"] == 1440 and r["frames"] == 3 and r["beamsLeft"] < r["beamsAtStart"] - 100
