@@ -166,92 +166,143 @@ inline void bisect(const std::vector<float> &px, const std::vector<float> &py, s
 } // namespace sbt
 
 // px,py: position per particle slot; beams: per beam slot, endpoints as particle slots.
+// Everything after the bisection runs per particle or per tile on a few host threads, over a particle -> incident-beams
+// adjacency (r02: the serial version was 48-75 ms of a 1 M-particle upload).
 inline void sb_build_tiling(SbTiling &t, const std::vector<float> &px, const std::vector<float> &py,
                             const SbHostBeams &beams, uint32_t target)
 {
     const uint32_t P = (uint32_t)px.size(), B = (uint32_t)beams.size();
     target = std::max(64u, std::min(target, 16384u));
     sbt::bisect(px, py, t.order, t.tile_p0, target);
-    t.ntiles = (uint32_t)t.tile_p0.size() - 1;
-    std::vector<uint32_t> internal_of_slot(P), tile_of(P);
-    for (uint32_t i = 0; i < P; i++) internal_of_slot[t.order[i]] = i;
-    for (uint32_t k = 0; k < t.ntiles; k++)
-        for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = k;
-
-    // pass 1: count copies and collect halo candidates per tile
-    std::vector<uint32_t> ncopy(t.ntiles + 1, 0);
-    std::vector<std::vector<uint32_t>> halo(t.ntiles);
-    t.cut_beams = 0;
-    for (uint32_t s = 0; s < B; s++) {
-        uint32_t ia = internal_of_slot[beams[s].a], ib = internal_of_slot[beams[s].b];
-        uint32_t ta = tile_of[ia], tb = tile_of[ib];
-        ncopy[ta]++;
-        if (tb != ta) {
-            ncopy[tb]++;
-            halo[ta].push_back(ib);
-            halo[tb].push_back(ia);
-            t.cut_beams++;
+    const uint32_t T = t.ntiles = (uint32_t)t.tile_p0.size() - 1;
+    sbt::uvec<uint32_t> internal_of_slot(P), tile_of(P);
+    sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) internal_of_slot[t.order[i]] = (uint32_t)i;
+    });
+    sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++)
+            for (uint32_t i = t.tile_p0[k]; i < t.tile_p0[k + 1]; i++) tile_of[i] = (uint32_t)k;
+    });
+    // endpoints as internal indices; adjacency (filled with atomic cursors: the order inside a list is arbitrary, each
+    // particle puts its OUT-beams, those with A == it, in slot order at the front of its list below)
+    sbt::uvec<uint32_t> ba(B), bb(B);
+    std::vector<uint32_t> adj0(P + 1, 0);
+    sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
+        for (size_t s = s0; s < s1; s++) {
+            ba[s] = internal_of_slot[beams[s].a];
+            bb[s] = internal_of_slot[beams[s].b];
+            __atomic_fetch_add(&adj0[ba[s] + 1], 1u, __ATOMIC_RELAXED);
+            if (bb[s] != ba[s]) __atomic_fetch_add(&adj0[bb[s] + 1], 1u, __ATOMIC_RELAXED);
         }
+    });
+    sbt::parallel_csr_scan(adj0);
+    sbt::uvec<uint32_t> adj(adj0[P]), out_deg(P);
+    {
+        sbt::uvec<uint32_t> cur(P);
+        sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) { std::copy(adj0.begin() + i0, adj0.begin() + i1, cur.begin() + i0); });
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
+            for (size_t s = s0; s < s1; s++) {
+                adj[__atomic_fetch_add(&cur[ba[s]], 1u, __ATOMIC_RELAXED)] = (uint32_t)s;
+                if (bb[s] != ba[s]) adj[__atomic_fetch_add(&cur[bb[s]], 1u, __ATOMIC_RELAXED)] = (uint32_t)s;
+            }
+        });
     }
-    t.tile_h0.assign(t.ntiles + 1, 0);
-    t.tile_b0.assign(t.ntiles + 1, 0);
-    t.max_own = t.max_all = 0;
-    for (uint32_t k = 0; k < t.ntiles; k++) {
-        auto &h = halo[k];
-        std::sort(h.begin(), h.end());
-        h.erase(std::unique(h.begin(), h.end()), h.end());
-        t.tile_h0[k + 1] = t.tile_h0[k] + (uint32_t)h.size();
-        t.tile_b0[k + 1] = t.tile_b0[k] + (ncopy[k] + 3) / 4 * 4;
-        uint32_t own = t.tile_p0[k + 1] - t.tile_p0[k];
-        t.max_own = std::max(t.max_own, own);
-        t.max_all = std::max(t.max_all, own + (uint32_t)h.size());
-    }
-    t.halo_idx.resize(t.tile_h0[t.ntiles]);
-    for (uint32_t k = 0; k < t.ntiles; k++) std::copy(halo[k].begin(), halo[k].end(), t.halo_idx.begin() + t.tile_h0[k]);
+    sbt::parallel_ranges(P, 1 << 14, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            uint32_t *l = adj.data() + adj0[i];
+            const uint32_t n = adj0[i + 1] - adj0[i];
+            uint32_t m = 0;
+            for (uint32_t e = 0; e < n; e++)
+                if (ba[l[e]] == i) std::swap(l[m++], l[e]);
+            std::sort(l, l + m);      // out-beams in slot order: position = RANK among the beams that leave this particle
+            std::sort(l + m, l + n);  // (in-beams in slot order too: the plan does not depend on thread timing)
+            out_deg[i] = m;
+        }
+    });
 
-    // pass 2: the copies of every tile, ordered by the beam's RANK among the beams that leave its endpoint A (0 = A's first
+    // pass 1, per tile: halo = the other endpoints of its particles' beams that live elsewhere; number of copies = every
+    // beam that leaves one of its particles + every beam that arrives from another tile
+    std::vector<std::vector<uint32_t>> halo(T);
+    std::vector<uint32_t> ncopy(T, 0), ncut(T, 0);
+    sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            auto &h = halo[k];
+            uint32_t copies = 0, cut = 0;
+            for (uint32_t p = t.tile_p0[k]; p < t.tile_p0[k + 1]; p++)
+                for (uint32_t e = adj0[p]; e < adj0[p + 1]; e++) {
+                    const uint32_t s = adj[e], q = ba[s] == p ? bb[s] : ba[s];
+                    const bool away = tile_of[q] != k;
+                    if (away) h.push_back(q);
+                    if (ba[s] == p) copies++;
+                    else if (away) copies++, cut++; // (a beam between two particles of this tile is A's alone)
+                }
+            std::sort(h.begin(), h.end());
+            h.erase(std::unique(h.begin(), h.end()), h.end());
+            ncopy[k] = copies;
+            ncut[k] = cut;
+        }
+    });
+    t.tile_h0.assign(T + 1, 0);
+    t.tile_b0.assign(T + 1, 0);
+    t.max_own = t.max_all = 0;
+    t.cut_beams = 0;
+    for (uint32_t k = 0; k < T; k++) {
+        t.tile_h0[k + 1] = t.tile_h0[k] + (uint32_t)halo[k].size();
+        t.tile_b0[k + 1] = t.tile_b0[k] + (ncopy[k] + 3) / 4 * 4;
+        const uint32_t own = t.tile_p0[k + 1] - t.tile_p0[k];
+        t.max_own = std::max(t.max_own, own);
+        t.max_all = std::max(t.max_all, own + (uint32_t)halo[k].size());
+        t.cut_beams += ncut[k];
+    }
+    t.halo_idx.resize(t.tile_h0[T]);
+
+    // pass 2, per tile: its copies, ordered by the beam's RANK among the beams that leave its endpoint A (0 = A's first
     // beam in slot order, 1 = its second ...) and then by A -- not by slot.  In slot order a particle's three or four beams
     // sit next to each other, so consecutive lanes of the kernel gather the same LDS position and add to the same LDS force
     // words: 43 % of the LDS cycles of k_substep_tiled were bank conflicts (r01 counters).  By rank, consecutive lanes work
     // on consecutive particles ("all the +y beams, then all the +x beams, then the diagonals").  The integer force sums do
     // not care about the order, so the result keeps its bits.
-    const uint32_t total = t.tile_b0[t.ntiles];
-    struct Copy { uint64_t key; uint32_t la, lb, slot, own; };
-    sbt::uvec<Copy> tmp(total);
-    std::vector<uint32_t> cursor(t.tile_b0.begin(), t.tile_b0.end() - 1), out_cnt(P, 0);
-    auto local = [&](uint32_t tile, uint32_t internal) -> uint32_t {
-        if (tile_of[internal] == tile) return internal - t.tile_p0[tile];
-        const auto &h = halo[tile];
-        uint32_t pos = (uint32_t)(std::lower_bound(h.begin(), h.end(), internal) - h.begin());
-        return (t.tile_p0[tile + 1] - t.tile_p0[tile]) + pos;
-    };
-    for (uint32_t s = 0; s < B; s++) {
-        const uint32_t ia = internal_of_slot[beams[s].a], ib = internal_of_slot[beams[s].b];
-        const uint32_t ta = tile_of[ia], tb = tile_of[ib];
-        const uint64_t rank = out_cnt[ia]++;
-        const uint32_t la = local(ta, ia);
-        tmp[cursor[ta]++] = Copy{(rank << 32) | la, la, local(ta, ib), s, 1u};
-        if (tb != ta) {
-            const uint32_t lb_a = local(tb, ia);
-            tmp[cursor[tb]++] = Copy{(rank << 32) | lb_a, lb_a, local(tb, ib), s, 0u};
-        }
-    }
+    const uint32_t total = t.tile_b0[T];
     t.copy_la.resize(total);
     t.copy_lb.resize(total);
     t.copy_slot.resize(total);
-    t.copy_of_slot.assign(B, 0);
-    sbt::parallel_ranges(t.ntiles, 16, [&](size_t k0, size_t k1) {
+    t.copy_of_slot.resize(B);
+    sbt::parallel_ranges(T, 16, [&](size_t k0, size_t k1) {
+        struct Copy { uint64_t key; uint32_t la, lb, slot, own; };
+        std::vector<Copy> tmp;
         for (size_t k = k0; k < k1; k++) {
-            const uint32_t c0 = t.tile_b0[k], c1 = cursor[k], c2 = t.tile_b0[k + 1];
-            std::sort(tmp.begin() + c0, tmp.begin() + c1,
-                      [](const Copy &x, const Copy &y) { return x.key != y.key ? x.key < y.key : x.slot < y.slot; });
-            for (uint32_t c = c0; c < c1; c++) {
-                t.copy_la[c] = tmp[c].la;
-                t.copy_lb[c] = tmp[c].lb;
-                t.copy_slot[c] = tmp[c].slot;
-                if (tmp[c].own) t.copy_of_slot[tmp[c].slot] = c;
+            const auto &h = halo[k];
+            std::copy(h.begin(), h.end(), t.halo_idx.begin() + t.tile_h0[k]);
+            const uint32_t p0 = t.tile_p0[k], n_own = t.tile_p0[k + 1] - p0;
+            auto local = [&](uint32_t internal) -> uint32_t {
+                if (tile_of[internal] == k) return internal - p0;
+                return n_own + (uint32_t)(std::lower_bound(h.begin(), h.end(), internal) - h.begin());
+            };
+            tmp.clear();
+            for (uint32_t p = p0; p < p0 + n_own; p++) {
+                const uint32_t *l = adj.data() + adj0[p];
+                const uint32_t n = adj0[p + 1] - adj0[p], m = out_deg[p];
+                for (uint32_t e = 0; e < m; e++) // beams that leave p: rank e
+                    tmp.push_back(Copy{((uint64_t)e << 32) | (p - p0), p - p0, local(bb[l[e]]), l[e], 1u});
+                for (uint32_t e = m; e < n; e++) { // beams that arrive at p from another tile: the rank they have at their A
+                    const uint32_t s = l[e], a = ba[s];
+                    if (tile_of[a] == k) continue;
+                    const uint32_t *la_list = adj.data() + adj0[a];
+                    const uint32_t rank = (uint32_t)(std::lower_bound(la_list, la_list + out_deg[a], s) - la_list);
+                    const uint32_t la = local(a);
+                    tmp.push_back(Copy{((uint64_t)rank << 32) | la, la, p - p0, s, 0u});
+                }
             }
-            for (uint32_t c = c1; c < c2; c++) t.copy_la[c] = t.copy_lb[c] = t.copy_slot[c] = 0xFFFFFFFFu; // padding to a multiple of 4
+            std::sort(tmp.begin(), tmp.end(), [](const Copy &x, const Copy &y) { return x.key != y.key ? x.key < y.key : x.slot < y.slot; });
+            uint32_t c = t.tile_b0[k];
+            for (const Copy &q : tmp) {
+                t.copy_la[c] = q.la;
+                t.copy_lb[c] = q.lb;
+                t.copy_slot[c] = q.slot;
+                if (q.own) t.copy_of_slot[q.slot] = c;
+                c++;
+            }
+            for (; c < t.tile_b0[k + 1]; c++) t.copy_la[c] = t.copy_lb[c] = t.copy_slot[c] = 0xFFFFFFFFu; // padding to a multiple of 4
         }
     });
 }

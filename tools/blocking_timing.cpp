@@ -38,5 +38,12 @@ int main(int argc, char **argv)
         fprintf(stderr, "   K %u: beam evaluations x%.3f, particle integrations x%.3f, largest region %u, most entries %u\n", K, ev / ((double)K * beams.size()),
                 in / ((double)K * P), t.max_region, t.max_entries);
     }
+    for (int rep = 0; rep < 3; rep++) { // the single-substep tiling of the same scene (spatial-hash mode, block_substeps = 1)
+        SbTiling tl;
+        const auto t0 = std::chrono::steady_clock::now();
+        sb_build_tiling(tl, px, py, beams, 1024);
+        fprintf(stderr, "== tiling %.2f ms (tiles %u, copies %zu, cut %llu)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                tl.ntiles, tl.copy_slot.size(), (unsigned long long)tl.cut_beams);
+    }
     return 0;
 }
