@@ -85,6 +85,17 @@ def test_negative_yield_takes_the_single_substep_kernel(sb, oracle):
     assert_same(got, exp, "negative yield")
 
 
+def test_fallback_with_automatic_tile_size_keeps_the_particle_order(sb, oracle):
+    """The blocked plan picks its own tile size (here 256-particle tiles for 90 000 particles); when the scene then turns out
+    not to fit the blocked kernel (negative yield), the single-substep tiling must be made on the SAME bisection -- the
+    particles are already on the device in that order.  (r02: it was made for 1024-particle tiles.)"""
+    buf = sb.scenes.lattice_buffers(300, 300, d=25.0, origin=(100.0, 100.0), jitter=2.0, layout=2, yield_strain=-0.01, strain_limit=1e9,
+                                    velocity=(1.0, -2.0))
+    got, exp, info = both(sb, oracle, buf, K=0, n=12, bounds=9000.0, tile=0)
+    assert info["substeps_per_launch"] == 1 and info["tiles"] > 200
+    assert_same(got, exp, "fallback, automatic tile size")
+
+
 def test_block_depth_is_lowered_until_the_region_fits(sb, oracle):
     """K = 8 on 1024-particle tiles of a 4-beam lattice needs regions beyond the kernel's capacity: the engine lowers K
     and says so."""
