@@ -11,6 +11,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 OFF, ALLPAIRS, GRID = 0, 1, 2
+# SB_FUZZ_OFFSET=n shifts every seed by n (a soak run over other cases than the committed ones); SB_FUZZ_COUNT widens it
+import os
+SEED0 = int(os.environ.get("SB_FUZZ_OFFSET", "0"))
+NGRID = int(os.environ.get("SB_FUZZ_COUNT", "64"))
 
 
 def make_case(sb, seed):
@@ -58,7 +62,7 @@ def make_case(sb, seed):
     return buf, bounds, consts, ui.user_input_bytes(), int(rng.choice([64, 128])), int(rng.integers(3, 8))
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + NGRID))
 def test_random_scene_grid_equals_allpairs(sb, oracle, seed):
     buf, bounds, consts, ui, tile, chunks = make_case(sb, seed)
     path = 1 + seed % 2
@@ -129,7 +133,7 @@ def make_beam_case(sb, seed):
     return buf, bounds, consts, ui.user_input_bytes(), int(rng.choice([64, 160, 512])), int(rng.integers(1, 9))
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(NGRID // 2, 1)))
 def test_random_beam_scene_blocked_equals_oracle(sb, oracle, seed):
     """Seeded fuzzing of the temporally blocked kernel: random block depth (1-8), tile size, scene and constants, odd
     substep counts with frames (delete passes) in between; bit for bit at every checkpoint, mapping included."""
