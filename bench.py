@@ -175,6 +175,25 @@ def committed_traffic(workload, kernel, key="bench"):
     return best
 
 
+def committed_valu(workload, kernel):
+    """VALU instructions per launch of `kernel` (whole waves, SQ_INSTS_VALU) from the newest committed SQ-counter pass of this
+    command (profiles/rNN_summary.json `sq_counters`), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            s = json.load(open(f))
+            if s.get("bench", {}).get("config", {}).get("workload") != workload:
+                continue
+            cand = [(t["SQ_INSTS_VALU"]["launches"], t["SQ_INSTS_VALU"]["per_launch"]) for name, t in s.get("sq_counters", {}).items()
+                    if name.startswith(kernel + "<") and "SQ_INSTS_VALU" in t]
+            if cand:
+                best = (max(cand)[1], os.path.basename(f))
+        except Exception:
+            continue
+    return best
+
+
 def peer_exchanger(halo, eng, plan, buf, dist, torch, ctl):
     """Direct neighbour exchange (sb_peer_*), agreed on by ALL ranks or by none: every rank sets its
     mailbox up, maps its neighbours', runs one refresh on the freshly uploaded state (where it must
@@ -262,6 +281,16 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
         roof["traffic"] = tr[0]
         roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
         roof["traffic_over_compulsory"] = tr[0] / (own * k)
+    if k > 1:
+        # the temporally blocked kernel is bound by instruction issue, not by HBM: the second roof it is
+        # measured against.  1024 SIMDs issue one wave64 fp32 instruction per 2.8 cycles with four waves each (tools/valu_rate.hip)
+        va = committed_valu(workload, roof["kernel"].split("<")[0])
+        if va:
+            simds, clock_hz, cycles_per_inst = 1024, 2.4e9, 2.8
+            roof["valu_issue"] = {"insts_per_launch": va[0], "source": "profiles/%s sq_counters (SQ_INSTS_VALU)" % va[1],
+                                  "frac_of_issue_peak": va[0] * cycles_per_inst / (simds * clock_hz * per_substep_s * k),
+                                  "note": "wave instructions x 2.8 cycles / (1024 SIMDs x 2.4 GHz x launch time); the launch's "
+                                          "load/store phase (about a third of it) issues almost nothing"}
     return roof
 
 
