@@ -407,3 +407,40 @@ def gather_owned(plan, buf):
     """(global particle ids, particle rows, global beam keys, beam records) of what this rank owns."""
     op, ob = plan.owned_particles, plan.owned_beams
     return (plan.global_particle_id[op], buf.particles[op], plan.global_beam_key[ob], buf.beams[ob])
+
+
+def owned_state(plan, buf):
+    """What a rank contributes to the gathered scene: (global particle ids, particle rows, global beam keys, their dynamic
+    fields, which of them are still in the mapping)."""
+    op, ob = plan.owned_particles, plan.owned_beams
+    live = np.zeros(buf.max_beams, bool)
+    live[buf.mapping[buf.max_particles:buf.max_particles + buf.beam_count].astype(np.int64)] = True
+    dyn = np.stack([buf.beams[f][ob] for f in ("target_length", "last_length", "strain", "stress")], axis=1).astype("<f4")
+    return (plan.global_particle_id[op], buf.particles[op].copy(), plan.global_beam_key[ob], dyn, live[ob])
+
+
+def repartition(gbuf, states, world, depth, contact_reach=0.0, ranks=None):
+    """Ownership does not migrate by itself: the slabs and ghost zones are those of the partition, so free particles that
+    wander into another rank's territory stop being seen by that rank's owners.  The remedy is to partition
+    again from the current state: `gbuf` is the global scene the run was partitioned from (layout.Buffers; brought up to
+    date IN PLACE -- particle rows, the beams' dynamic fields, removed beams taken out of the mapping by stable
+    compaction, as compute_delete does), `states` = owned_state(plan, loaded buffers) of EVERY rank (an all-gather in a real
+    run: a few tens of bytes per particle and beam).  Returns partition_scene() of the updated scene.  Call it BETWEEN
+    frames: beams flagged since the last delete pass are engine state that an upload does not carry.  Every rank then
+    uploads its new scene and builds a new Exchanger (a new upload starts a new mailbox)."""
+    seen = np.zeros(gbuf.max_particles, bool)
+    dead = np.zeros(gbuf.max_beams, bool)
+    for gid, rows, bkey, dyn, live in states:
+        assert not seen[gid].any(), "two ranks own the same particle"
+        seen[gid] = True
+        gbuf.particles[gid] = rows
+        for k, f in enumerate(("target_length", "last_length", "strain", "stress")):
+            gbuf.beams[f][bkey] = dyn[:, k]
+        dead[bkey[~np.asarray(live, bool)]] = True
+    P0, n = gbuf.max_particles, gbuf.beam_count
+    slots = gbuf.mapping[P0:P0 + n]
+    keep = slots[~dead[slots.astype(np.int64)]]
+    gbuf.mapping[P0:P0 + keep.size] = keep
+    gbuf.beam_count = int(keep.size)
+    return partition_scene(gbuf, world, depth, contact_reach, ranks)
+

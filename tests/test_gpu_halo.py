@@ -362,3 +362,56 @@ def test_partitioned_scene_on_engines_equals_single_engine(sb, world, mode):
             assert rec.tobytes()[8:] == want.beams[int(k)].tobytes()[8:]
         seen += gid.size
     assert seen == buf.particle_count and not np.array_equal(want.particles, buf.particles)
+
+
+def test_repartition_on_engines_follows_two_clouds_through_each_other(sb):
+    """halo.repartition() with real engines (spatial-hash collisions): two clouds of free particles that share no ghosts at
+    the start fly through each other; re-partitioned after every frame (gather the owned state, partition, upload), the two
+    ranks reproduce the single engine bit for bit."""
+    import torch
+    from halo_oracle import LocalBus, frame_all
+    from test_partition_cpu import two_clouds
+    halo = sb.halo
+    world, depth, reach, frames = 2, 2, 80.0, 9
+    gbuf = two_clouds(sb)
+
+    def engine_for(buf):
+        e = sb.Engine(bounds_size=1000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=2)
+        e.write_buffers(buf)
+        return e
+
+    ref = engine_for(gbuf)
+    for _ in range(frames):
+        ref.frame()
+    want = ref.load_buffers(gbuf.copy())
+    ref.destroy()
+    dev = torch.device("cuda", 0)
+
+    def build(made):
+        bus, exs, engs = LocalBus(), [], []
+        for r, (lbuf, plan) in enumerate(made):
+            eng = engine_for(lbuf)
+            tr = bus.transport(r, lambda a, b: (torch.zeros(max(a, 1), device=dev), torch.zeros(max(b, 1), device=dev)),
+                               lambda t: t.data_ptr())
+            exs.append(halo.Exchanger(eng, plan, tr))
+            engs.append(eng)
+        return bus, exs, engs
+
+    made = halo.partition_scene(gbuf, world, depth, contact_reach=reach)
+    bus, exs, engs = build(made)
+    for f in range(frames):
+        def sync():
+            for e in engs:
+                e.sync()
+            torch.cuda.synchronize()
+        frame_all(exs, bus, lambda dst, src: dst.copy_(src), sync)
+        states = [halo.owned_state(plan, eng.load_buffers(lbuf.copy())) for (lbuf, plan), eng in zip(made, engs)]
+        for e in engs:
+            e.destroy()
+        made = halo.repartition(gbuf, states, world, depth, reach)
+        if f + 1 < frames:
+            bus, exs, engs = build(made)
+    P = gbuf.particle_count
+    assert np.array_equal(gbuf.particles[:P].view("u4"), want.particles[:P].view("u4"))       # gbuf IS the gathered state now
+    assert sum(p.ghost_p.size for _, plan in made for p in plan.peers) > 40
+

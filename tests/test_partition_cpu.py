@@ -106,6 +106,106 @@ def test_partitioned_pile_with_contacts_across_the_faces(sb, oracle):
     assert any(lbuf.particle_count < buf.particle_count for lbuf, _ in made)                      # and it is a real split
 
 
+def two_clouds(sb):
+    """two clouds of free particles flying at each other: 200 apart at the start, through each other by frame 9"""
+    rng = np.random.default_rng(5)
+    pts = []
+    for cx, vx in ((250.0, 20.0), (750.0, -20.0)):
+        for i in range(10):
+            for j in range(12):
+                pts.append((cx - 150 + 30.0 * i + rng.uniform(-3, 3), 40.0 + 30.0 * j + rng.uniform(-3, 3), vx + rng.uniform(-2, 2),
+                            rng.uniform(-2, 2), 0, 0))
+    buf = sb.Buffers(2, len(pts) + 8, 16)
+    buf.set_scene(np.array(pts, "f4"), np.zeros(0, sb.layout.BEAM_DTYPE[2]))
+    return buf
+
+
+@pytest.mark.parametrize("again", [True, False])
+def test_repartition_lets_ownership_follow_the_particles(sb, oracle, again):
+    """Ghost zones are those of the partition: two clouds that start 200 apart share no ghosts (contact band 80), so on
+    their own ranks they fly through each other.  halo.repartition() between frames -- gather the owned state, partition
+    again -- keeps the run bit-identical to the single engine through the whole collision; without it the run diverges
+    (the negative control)."""
+    from halo_oracle import LocalBus, OracleRank, frame_all
+    halo = sb.halo
+    world, depth, reach, frames, mode = 2, 2, 80.0, 9, oracle.COLLIDE_GRID
+    gbuf = two_clouds(sb)
+    ref = OracleRank(oracle, gbuf, 1000.0, mode=mode)
+    for _ in range(frames):
+        ref.ref.frame()
+    want = ref.load(gbuf)
+
+    def build(made):
+        bus, exs, engs = LocalBus(), [], []
+        for r, (lbuf, plan) in enumerate(made):
+            eng = OracleRank(oracle, lbuf, 1000.0, mode=mode)
+            tr = bus.transport(r, lambda a, b: (np.zeros(max(a, 1), "f4"), np.zeros(max(b, 1), "f4")), lambda t: t)
+            exs.append(halo.Exchanger(eng, plan, tr))
+            engs.append(eng)
+        return bus, exs, engs
+
+    made = halo.partition_scene(gbuf, world, depth, contact_reach=reach)
+    assert all(not p.ghost_p.size for _, plan in made for p in plan.peers)        # nothing in common at the start
+    bus, exs, engs = build(made)
+    for _ in range(frames):
+        frame_all(exs, bus, lambda dst, src: dst.__setitem__(slice(None), src))
+        if again:
+            states = [halo.owned_state(plan, eng.load(lbuf)) for (lbuf, plan), eng in zip(made, engs)]
+            made = halo.repartition(gbuf, states, world, depth, reach)
+            bus, exs, engs = build(made)
+    got = np.zeros_like(want.particles)
+    for (lbuf, plan), eng in zip(made, engs):
+        out = eng.load(lbuf)
+        got[plan.global_particle_id[plan.owned_particles]] = out.particles[plan.owned_particles]
+    P = gbuf.particle_count
+    same = np.array_equal(got[:P].view("u4"), want.particles[:P].view("u4"))
+    if again:
+        assert same and sum(p.ghost_p.size for _, plan in made for p in plan.peers) > 40   # the clouds are in each other's zones now
+    else:
+        assert not same and np.abs(got[:P, :2] - want.particles[:P, :2]).max() > 10.0
+
+
+def test_repartition_carries_beam_state_and_removed_beams(sb, oracle):
+    """A lattice whose beams yield and break, partitioned in three, re-partitioned after every frame: the new scenes carry
+    target / last lengths and leave the removed beams out of the mapping (stable compaction, as compute_delete does), and the
+    merged run stays bit-identical to the single engine."""
+    from halo_oracle import LocalBus, OracleRank, frame_all
+    halo = sb.halo
+    world, depth, frames = 3, 3, 4
+    gbuf = sb.scenes.lattice_buffers(18, 7, d=25.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), layout=2, strain_limit=0.02)
+    ref = OracleRank(oracle, gbuf, 1000.0)
+    for _ in range(frames):
+        ref.ref.frame()
+    want = ref.load(gbuf)
+    assert want.beam_count < gbuf.beam_count - 50
+
+    def build(made):
+        bus, exs, engs = LocalBus(), [], []
+        for r, (lbuf, plan) in enumerate(made):
+            eng = OracleRank(oracle, lbuf, 1000.0)
+            tr = bus.transport(r, lambda a, b: (np.zeros(max(a, 1), "f4"), np.zeros(max(b, 1), "f4")), lambda t: t)
+            exs.append(halo.Exchanger(eng, plan, tr))
+            engs.append(eng)
+        return bus, exs, engs
+
+    cur = gbuf.copy()
+    made = halo.partition_scene(cur, world, depth)
+    bus, exs, engs = build(made)
+    for _ in range(frames):
+        frame_all(exs, bus, lambda dst, src: dst.__setitem__(slice(None), src))
+        states = [halo.owned_state(plan, eng.load(lbuf)) for (lbuf, plan), eng in zip(made, engs)]
+        made = halo.repartition(cur, states, world, depth)
+        bus, exs, engs = build(made)
+    # `cur` is the gathered scene now: same particles, same surviving beams in the same slot order, same beam records
+    P = gbuf.particle_count
+    assert np.array_equal(cur.particles[:P].view("u4"), want.particles[:P].view("u4"))
+    assert cur.beam_count == want.beam_count
+    P0 = gbuf.max_particles
+    assert np.array_equal(cur.mapping[P0:P0 + cur.beam_count], want.mapping[P0:P0 + want.beam_count])
+    live = want.mapping[P0:P0 + want.beam_count].astype(np.int64)
+    assert cur.beams[live].tobytes() == want.beams[live].tobytes()
+
+
 def test_partition_argument_checks(sb):
     buf = sb.scenes.default_buffers(2, 256, 512)
     with pytest.raises(sb.engine.EngineError, match="depth 0"):
