@@ -8,7 +8,8 @@
  * IPC-mapped device mailboxes (sb_peer_* in include/softbody.h; no collective library, no host copy).
  *   partitionScene(mapperOrBuffers, world, depth, contactReach)   any scene -> per-rank scenes + plans (C library: sb_partition_*)
  *   HaloPlan                                                       who owns what on a rank, what it trades with whom
- *   PeerExchanger                                                  mailbox set-up, connect, step(n) with a refresh every depth substeps
+ *   PeerExchanger                                                  mailbox set-up, connect, step(n) with a refresh every depth substeps, frame()
+ *   ownedState / repartition                                       ownership follows the particles: partition again from the gathered state
  * The same three pieces exist for the Python harness in softbody-webgpu_amd/halo.py; both call the same C code.
  */
 const { native } = require('./native');
@@ -186,4 +187,65 @@ class PeerExchanger {
     }
 }
 
-module.exports = { HaloPlan, PeerExchanger, partitionScene };
+const layoutOf = (scene) => {
+    const id = typeof scene.layout === 'object' ? scene.layout.id : scene.layout;
+    return { id, beamStride: id === 1 ? 40 : 44, floats: id === 1 ? 4 : 8, indexBytes: id === 1 ? 2 : 4 };
+};
+const DYN = [1, 2, 7, 8]; // target_length, last_length, strain, stress among a beam record's nine floats
+
+/**
+ * What a rank contributes to the gathered scene (halo.py owned_state): the rows of the particles it owns, the dynamic
+ * fields of the beams it owns, and which of those beams are still in the mapping.  `local` is the rank's scene (a RankScene
+ * of partitionScene) with its four buffers as read back from the engine; plain typed arrays, so the result survives
+ * structured clone / JSON (Array.from) on its way to the other processes.
+ */
+function ownedState(plan, local) {
+    const L = layoutOf(local), f = new Float32Array(local.particleData), md = new DataView(local.metadata);
+    const beamCount = md.getUint32(24, true);
+    const map = L.indexBytes === 2 ? new Uint16Array(local.mapping) : new Uint32Array(local.mapping);
+    const alive = new Uint8Array(local.maxBeams);
+    for (let s = 0; s < beamCount; s++) alive[map[local.maxParticles + s]] = 1;
+    const op = plan.ownedParticles, ob = plan.ownedBeams, bv = new DataView(local.beamData);
+    const particleIds = new Uint32Array(op.length), particleRows = new Float32Array(6 * op.length);
+    op.forEach((i, k) => { particleIds[k] = plan.globalParticleId[i]; particleRows.set(f.subarray(6 * i, 6 * i + 6), 6 * k); });
+    const beamKeys = new Uint32Array(ob.length), beamDyn = new Float32Array(4 * ob.length), live = new Uint8Array(ob.length);
+    ob.forEach((j, k) => {
+        beamKeys[k] = plan.globalBeamKey[j];
+        DYN.forEach((w, q) => { beamDyn[4 * k + q] = bv.getFloat32(j * L.beamStride + L.floats + 4 * w, true); });
+        live[k] = alive[j];
+    });
+    return { particleIds, particleRows, beamKeys, beamDyn, live };
+}
+
+/**
+ * Ownership does not migrate by itself (DESIGN.md 5): partition again from the current state.  `scene` is the GLOBAL scene the
+ * run was partitioned from (brought up to date in place: particle rows, the beams' dynamic fields, removed beams taken out
+ * of the mapping by stable compaction, as compute_delete does); `states` = ownedState() of EVERY rank.  Call it between
+ * frames; every rank then uploads its new scene and builds a new PeerExchanger.  (halo.py repartition.)
+ */
+function repartition(scene, states, world, depth, contactReach, ranks) {
+    const L = layoutOf(scene), f = new Float32Array(scene.particleData), bv = new DataView(scene.beamData), md = new DataView(scene.metadata);
+    const dead = new Uint8Array(scene.maxBeams), seen = new Uint8Array(scene.maxParticles);
+    for (const st of states) {
+        st.particleIds.forEach((g, k) => {
+            if (seen[g]) throw new Error('two ranks own particle ' + g);
+            seen[g] = 1;
+            for (let q = 0; q < 6; q++) f[6 * g + q] = st.particleRows[6 * k + q];
+        });
+        st.beamKeys.forEach((g, k) => {
+            DYN.forEach((w, q) => bv.setFloat32(g * L.beamStride + L.floats + 4 * w, st.beamDyn[4 * k + q], true));
+            if (!st.live[k]) dead[g] = 1;
+        });
+    }
+    const map = L.indexBytes === 2 ? new Uint16Array(scene.mapping) : new Uint32Array(scene.mapping);
+    const n = md.getUint32(24, true);
+    let w = 0;
+    for (let s = 0; s < n; s++) {
+        const idx = map[scene.maxParticles + s];
+        if (!dead[idx]) map[scene.maxParticles + w++] = idx;
+    }
+    md.setUint32(24, w, true);
+    return partitionScene(scene, world, depth, contactReach, ranks);
+}
+
+module.exports = { HaloPlan, PeerExchanger, partitionScene, ownedState, repartition };

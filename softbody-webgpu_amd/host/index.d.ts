@@ -230,6 +230,13 @@ export type RankScene = { readonly rank: number, readonly layout: 1 | 2, readonl
 export function partitionScene(scene: BufferMapper | { layout: 1 | 2, maxParticles: number, maxBeams: number, metadata: ArrayBuffer,
     mapping: ArrayBuffer, particleData: ArrayBuffer, beamData: ArrayBuffer }, world: number, depth: number, contactReach?: number,
     ranks?: number[]): RankScene[];
+/** a rank's share of the gathered scene: rows of its own particles, dynamic fields of its own beams, which of them are left */
+export type OwnedState = { readonly particleIds: Uint32Array, readonly particleRows: Float32Array, readonly beamKeys: Uint32Array,
+    readonly beamDyn: Float32Array, readonly live: Uint8Array };
+export function ownedState(plan: HaloPlan, local: RankScene): OwnedState;
+/** partition again from the current state (between frames): updates `scene` in place from every rank's ownedState(), then partitionScene() */
+export function repartition(scene: Parameters<typeof partitionScene>[0], states: OwnedState[], world: number, depth: number,
+    contactReach?: number, ranks?: number[]): RankScene[];
 export type PeerCard = { readonly rank: number, readonly pid: number, readonly pointer: number, readonly handle: number[],
     readonly recvFloats: number, readonly recv: [number, number, number][] };
 export class PeerExchanger {

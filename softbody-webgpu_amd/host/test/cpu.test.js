@@ -158,5 +158,38 @@ const same = (ab, file) => Buffer.compare(Buffer.from(ab), fs.readFileSync(path.
         for (const f of ['haloConfigure', 'haloSetLayout', 'peerMailbox', 'peerMap', 'peerConnect', 'peerExchange', 'getStream'])
             assert.strictEqual(typeof a[f], 'function', f);
     });
+    test('repartition: gathered state back into the global scene, removed beams compacted out, same partition again', () => {
+        const m = h.defaultScene(new h.BufferMapper(1 << 27, { layout: 2, maxParticles: 256, maxBeams: 512 }));
+        m.writeState();
+        const before = { particles: new Uint8Array(m.particleData).slice(), beams: new Uint8Array(m.beamData).slice() };
+        const ranks = h.partitionScene(m, 3, 2, 0);
+        // every rank moves its own particles by its rank number and "loses" the beam with the lowest key it owns
+        const gone = [];
+        const states = ranks.map((r) => {
+            const f = new Float32Array(r.particleData);
+            for (const i of r.plan.ownedParticles) f[6 * i] += 1 + r.rank;
+            const st = h.ownedState(r.plan, r);
+            st.live[0] = 0;
+            gone.push(st.beamKeys[0]);
+            st.beamDyn[1] = 123.5; // last_length of that beam
+            return st;
+        });
+        const again = h.repartition(m, states, 3, 2, 0);
+        assert.strictEqual(new DataView(m.metadata).getUint32(24, true), 299 - 3);
+        const map = new Uint32Array(m.mapping), left = Array.from(map.subarray(m.maxParticles, m.maxParticles + 296));
+        for (const g of gone) assert.ok(!left.includes(g));
+        assert.deepStrictEqual(left, Array.from({ length: 299 }, (_, k) => k).filter((k) => !gone.includes(k)));   // stable
+        const f = new Float32Array(m.particleData), f0 = new Float32Array(before.particles.buffer);
+        for (const r of ranks) for (const i of r.plan.ownedParticles) {
+            const g = r.plan.globalParticleId[i];
+            assert.strictEqual(f[6 * g], Math.fround(f0[6 * g] + 1 + r.rank));
+            assert.strictEqual(f[6 * g + 1], f0[6 * g + 1]);
+        }
+        assert.strictEqual(new DataView(m.beamData).getFloat32(gone[0] * 44 + 8 + 8, true), 123.5);
+        assert.strictEqual(again.length, 3);
+        assert.strictEqual(again.reduce((n, r) => n + r.plan.ownedBeams.length, 0), 296);
+        assert.strictEqual(again.reduce((n, r) => n + r.plan.nOwned, 0), 119);
+        assert.throws(() => h.repartition(m, [states[0], states[0]], 3, 2, 0), /two ranks own/);
+    });
     console.log(JSON.stringify({ passed: results.length, failed: process.exitCode ? 1 : 0, names: results }));
 })();

@@ -28,7 +28,7 @@ def test_js_host_cpu():
     loud failure without a GPU."""
     import torch
     r = run_node("cpu.test.js", {"SOFTBODY_EXPECT_NO_GPU": "0" if torch.cuda.is_available() else "1"})
-    assert r["failed"] == 0 and r["passed"] == 11
+    assert r["failed"] == 0 and r["passed"] == 12
 
 
 @needs_node
