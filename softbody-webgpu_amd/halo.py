@@ -223,7 +223,10 @@ class Exchanger:
 
     def frame(self):
         """One frame on this rank: engine.subticks substeps with the usual refreshes, the delete pass of owned beams, one
-        more refresh that carries the deaths, the removal of the ghost copies.  Every rank calls it at the same time."""
+        more refresh that carries the deaths, the removal of the ghost copies.  Every rank calls it at the same time.
+        (It ends by reading the beam count, which waits for this rank's stream: ranks that live in ONE process and trade
+        through sb_peer_* must therefore be driven in lock step, phase by phase -- tests/halo_oracle.py frame_all -- or the
+        first rank waits for a neighbour whose kernels have not been enqueued yet.  One process per rank has no such issue.)"""
         self.step(self.engine.subticks)
         if not self.plan.peers:
             self.engine.delete_pass()
