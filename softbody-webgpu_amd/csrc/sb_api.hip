@@ -1047,6 +1047,23 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
     if (!e || !ms) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step_timed before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
+    static const bool graph_experiment = getenv("SB_GRAPH_EXPERIMENT") != nullptr; // measurement only: the same launches as ONE graph
+    if (graph_experiment) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        SB_HIP(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        launch_substeps(e, n);
+        SB_HIP(e, hipStreamEndCapture(e->stream, &g));
+        SB_HIP(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        SB_HIP(e, hipEventRecord(e->ev0, e->stream));
+        SB_HIP(e, hipGraphLaunch(ge, e->stream));
+        SB_HIP(e, hipEventRecord(e->ev1, e->stream));
+        SB_HIP(e, hipEventSynchronize(e->ev1));
+        SB_HIP(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+        (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+        return SB_OK;
+    }
     SB_HIP(e, hipEventRecord(e->ev0, e->stream));
     launch_substeps(e, n);
     SB_HIP(e, hipGetLastError());
