@@ -1,0 +1,46 @@
+"""bench.py's one JSON line (the driver's contract): the keys it must carry, the two extra objects, sane values -- on the real
+workload with few steps, and the N = 2 form started bare on one GPU (the ranks are child processes bench.py starts itself)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline", "cpu_baseline")
+
+
+def run_bench(*args, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout: %r" % p.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def test_default_line_carries_the_contract():
+    d = run_bench("--steps", "60", "--warmup", "12", "--cpu-seconds", "2")
+    for k in KEYS:
+        assert k in d, k
+    assert d["metric"] == "particle-steps/sec" and d["unit"] == "particle-steps/s" and d["n_gpus"] == 1 and d["steps"] == 60
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1_000_000 * 60 / (d["ms_per_step"] * 60 * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0.0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["value"] > 1.0e10                                   # BASELINE's target for config 2
+    ex = d["extra"]
+    assert ex["upload_ms"] > 0 and ex["readback_ms"] > 0 and ex["config3"]["value"] > 1.0e10 and ex["config3"]["finite"]
+    assert ex["single_substep_kernel"]["frac_of_hbm_peak"] > 0.4
+
+
+def test_two_ranks_started_bare_on_one_gpu():
+    d = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "120", "--warmup", "30")
+    assert d["n_gpus"] == 2 and d["value"] > 1.0e10 and "REHEARSAL" in d["data"]
