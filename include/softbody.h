@@ -86,8 +86,10 @@ typedef struct sb_options {
                               * fixed; negative = rebuild every substep */
     uint32_t block_substeps; /* SB_PATH_TILED with SB_COLLIDE_OFF: substeps one launch advances out of LDS and
                               * registers (temporal blocking over beam-hop rings; same bits as single substeps).
-                              * 0 = default (6), 1 = one launch per substep, at most 8; lowered
-                              * automatically until every tile's region fits the kernel's registers and LDS */
+                              * 0 = default: a plan 7 substeps deep, each call cut into the cheapest balanced
+                              * launches (long calls 6 per launch, 20 substeps as 7 + 7 + 6); N > 1 = every call in
+                              * the fewest launches of at most N (at most 8); 1 = one launch per substep.  Lowered
+                              * automatically to the deepest plan whose regions fit the kernel's registers and LDS */
     uint32_t reserved[3];
 } sb_options;
 
@@ -235,6 +237,9 @@ sb_status sb_partition_create(uint32_t layout, uint32_t max_particles, uint32_t 
 sb_status sb_partition_destroy(sb_partition *p);
 /* counts = { local particles, local beams, owned particles, owned beams, peers, depth, global particles, global beams } */
 sb_status sb_partition_rank_counts(const sb_partition *p, uint32_t rank, uint32_t counts[8]);
+/* the layout the partition was created with (SB_LAYOUT_V1 / SB_LAYOUT_V2): it fixes the record sizes of what
+ * sb_partition_rank_scene writes -- mapping indices of 2 or 4 bytes, beam records of SB_BEAM_STRIDE_V1 or _V2 bytes */
+sb_status sb_partition_layout(const sb_partition *p, uint32_t *layout);
 /* the rank's scene in the partition's layout, into caller buffers of the given capacities (>= the local counts) */
 sb_status sb_partition_rank_scene(const sb_partition *p, uint32_t rank, uint32_t max_particles, uint32_t max_beams, void *metadata,
                                   void *mapping, void *particles, void *beams);

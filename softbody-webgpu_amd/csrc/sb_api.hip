@@ -359,6 +359,12 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     k.entries = bl.ent_la.size();
     k.halo_entries = bl.ent_state.size();
     k.halo_particles = bl.halo_idx.size();
+    k.fixed_depth = e->opt.block_substeps != 0;
+    k.k_long = k.fixed_depth ? blockK : std::min<uint32_t>(blockK, SB_BK_KLONG);
+    for (uint32_t d = 1; d <= blockK; d++) {
+        k.entries_at[d] = bl.sum_entries_at[d];
+        k.region_at[d] = bl.sum_region_at[d];
+    }
     e->ntiles = T;
     e->nhalo = (uint32_t)bl.halo_idx.size();
     e->tile_cap_own = bl.max_own;
@@ -656,13 +662,21 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             target = (uint32_t)std::min<uint64_t>(1100u, std::max<uint64_t>(256u, (P + slots * rounds - 1) / (slots * rounds)));
         }
         if (want_blocked) {
-            // K substeps per launch, K as large as asked for while every tile's region still fits the kernel's
-            // per-thread register arrays and 12-bit local indices
+            // the plan is made as deep as asked for (default SB_BK_KPLAN) while every tile's region still fits the kernel's
+            // per-thread register arrays and 12-bit local indices.  One breadth-first search to the depth asked for tells the
+            // region and entry sizes of EVERY smaller depth (they are prefixes), so a plan that does not fit is re-made once, at
+            // the deepest depth that does -- not once per candidate (a dense scene used to pay up to six plan builds per upload)
             const uint32_t region_cap = std::min<uint32_t>(SB_BK_MAXP * SB_BK_T, (1u << SB_BK_LBITS) - 2u);
-            for (blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KDEFAULT, SB_BK_KMAX); blockK; blockK--) {
-                sb_build_blocking(bl, px, py, hb, target, blockK);
-                plan_target = target;
-                if (bl.max_region <= region_cap && bl.max_entries <= SB_BK_MAXB * SB_BK_T) break;
+            const uint32_t entry_cap = SB_BK_MAXB * SB_BK_T;
+            blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
+            sb_build_blocking(bl, px, py, hb, target, blockK);
+            plan_target = target;
+            if (!(bl.max_region <= region_cap && bl.max_entries <= entry_cap)) {
+                uint32_t fit = 0;
+                for (uint32_t d = 1; d < blockK; d++)
+                    if (bl.region_at[d] <= region_cap && bl.entries_at[d] <= entry_cap) fit = d;
+                blockK = fit;
+                if (blockK) sb_build_blocking(bl, px, py, hb, target, blockK);
             }
         }
         if (blockK) {
@@ -1047,23 +1061,6 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
     if (!e || !ms) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step_timed before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
-    static const bool graph_experiment = getenv("SB_GRAPH_EXPERIMENT") != nullptr; // measurement only: the same launches as ONE graph
-    if (graph_experiment) {
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        SB_HIP(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        launch_substeps(e, n);
-        SB_HIP(e, hipStreamEndCapture(e->stream, &g));
-        SB_HIP(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        SB_HIP(e, hipEventRecord(e->ev0, e->stream));
-        SB_HIP(e, hipGraphLaunch(ge, e->stream));
-        SB_HIP(e, hipEventRecord(e->ev1, e->stream));
-        SB_HIP(e, hipEventSynchronize(e->ev1));
-        SB_HIP(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
-        (void)hipGraphExecDestroy(ge);
-        (void)hipGraphDestroy(g);
-        return SB_OK;
-    }
     SB_HIP(e, hipEventRecord(e->ev0, e->stream));
     launch_substeps(e, n);
     SB_HIP(e, hipGetLastError());
@@ -1216,11 +1213,15 @@ static uint64_t substep_bytes_model(const sb_engine *e)
 {
     const uint64_t P = e->P, nc = e->nbeam;
     if (e->bk.K) {
-        // one launch = K substeps: every entry word, the state of every halo entry (index + target + last, gathered),
-        // the owned states in and out, own particles in and out, halo particles (index + position + velocity)
-        const uint64_t per_launch = e->bk.entries * (4 + (e->mat_mode == 1 ? 4 : 0)) + e->bk.halo_entries * 12 + nc * 16 + P * 32 +
-                                    e->bk.halo_particles * 20 + (uint64_t)e->ntiles * (8 * 4 + 8 * e->bk.K) + (uint64_t)e->nmat * 24;
-        return per_launch / e->bk.K;
+        // one launch of a long call = k_long substeps: every entry word of that depth, the state of every halo entry (index +
+        // target + last, gathered), the owned states in and out, own particles in and out, halo particles (index + position +
+        // velocity)
+        const uint32_t k = e->bk.k_long;
+        const uint64_t entries = e->bk.entries_at[k], halo_entries = entries - std::min<uint64_t>(entries, nc),
+                       halo_particles = e->bk.region_at[k] - std::min<uint64_t>(e->bk.region_at[k], P);
+        const uint64_t per_launch = entries * (4 + (e->mat_mode == 1 ? 4 : 0)) + halo_entries * 12 + nc * 16 + P * 32 +
+                                    halo_particles * 20 + (uint64_t)e->ntiles * (8 * 4 + 8 * k) + (uint64_t)e->nmat * 24;
+        return per_launch / k;
     }
     if (e->path == SB_PATH_TILED) {
         uint64_t per_copy = 4 /* endpoint word */ + 4 /* target */ + 4 + 4 /* last: read, written */;
@@ -1239,11 +1240,12 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     std::string k(key);
     if (k == "path") *value = e->path;
     else if (k == "substep_hbm_bytes") *value = substep_bytes_model(e);
-    else if (k == "substeps_per_launch") *value = e->bk.K ? e->bk.K : 1;
+    else if (k == "substeps_per_launch") *value = e->bk.K ? e->bk.k_long : 1; // of a long call (sbk_split_call)
+    else if (k == "plan_depth") *value = e->bk.K ? e->bk.K : 1;
     else if (k == "region_particles") *value = e->bk.K ? e->bk.cap : e->tile_cap_all;
     else if (k == "tiles") *value = e->ntiles;
-    else if (k == "beam_copies") *value = e->bk.K ? e->bk.entries : e->nbeam;
-    else if (k == "halo_particles") *value = e->bk.K ? e->bk.halo_particles : e->nhalo;
+    else if (k == "beam_copies") *value = e->bk.K ? e->bk.entries_at[e->bk.k_long] : e->nbeam;
+    else if (k == "halo_particles") *value = e->bk.K ? e->bk.region_at[e->bk.k_long] - e->P : e->nhalo;
     else if (k == "device_bytes") *value = e->device_bytes;
     else if (k == "substeps_done") *value = e->substeps_done;
     else if (k == "lds_bytes") *value = e->lds_bytes;

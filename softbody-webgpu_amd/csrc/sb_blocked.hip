@@ -51,15 +51,8 @@ struct SbBlockedState {
 template <int MAT, bool AUX>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
-    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, uint32_t dephase_lo, uint32_t dephase_hi, uint32_t dephase_ticks)
+    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
 {
-    // De-phasing: every workgroup of the first round starts at the same instant, so the whole chip loads, then computes,
-    // then stores in lock-step and HBM and the VALUs take turns idling.  The second half of the first round therefore
-    // starts late by about one load phase: it loads while the first half computes, and the rounds after it inherit the shift.
-    if (blockIdx.x >= dephase_lo && blockIdx.x < dephase_hi) {
-        const uint64_t t0 = wall_clock64();
-        while (wall_clock64() - t0 < dephase_ticks) __builtin_amdgcn_s_sleep(32);
-    }
     // static LDS layout: every address below is a register plus an immediate offset
     __shared__ float2 s_pos[SB_BK_CAP];
     __shared__ int s_fx[SB_BK_CAP], s_fy[SB_BK_CAP]; // fixed-point force sums (x and y apart: consecutive particles, consecutive banks)
@@ -339,24 +332,51 @@ __global__ __launch_bounds__(256) void k_delete_blocked(uint32_t *ent_word, cons
 
 static inline uint32_t cdiv_b(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// n substeps as ceil(n / K) launches; the last launch of a call also stores strain/stress when write_aux
+// How a call of n substeps is cut into launches of at most kmax substeps each.  A launch pays a fixed part (its load and
+// store phases, the boundary) and a part that grows a little faster than its depth (deeper rings: more redundant work), so
+// neither "as deep as possible" nor "always the sweet spot" is right: 20 substeps are cheaper as 7 + 7 + 6 than as
+// 6 + 6 + 6 + 2, 960 are cheaper as 160 x 6 than as 137 x 7 + 1.  Candidates are BALANCED splits (L launches of depth
+// ceil(n / L) or one less) for every L from the fewest possible on; they are priced with the launch times measured on
+// BASELINE config 2 (1 M particles, r02/r03 depth sweeps; the shape of the curve, not its scale, is what decides).
+// Returns L; *first = ceil(n / L), *n_first = how many launches have that depth (the others have first - 1).
+static const float kLaunchCostUs[SB_BK_KMAX + 1] = {0.0f, 30.0f, 38.0f, 48.0f, 58.5f, 69.0f, 79.2f, 93.8f, 109.0f};
+uint32_t sbk_split_call(uint32_t n, uint32_t kmax, bool fewest, uint32_t *first, uint32_t *n_first)
+{
+    kmax = kmax < 1u ? 1u : (kmax > SB_BK_KMAX ? SB_BK_KMAX : kmax);
+    uint32_t best_L = 0;
+    float best = 0.0f;
+    const uint32_t L_min = (n + kmax - 1) / kmax;
+    for (uint32_t L = L_min; L <= n && L <= (fewest ? L_min : L_min * 2u + 1u); L++) { // (beyond twice the fewest launches nothing gets cheaper)
+        const uint32_t hi = (n + L - 1) / L, n_hi = n - (hi - 1) * L;
+        const float cost = (float)n_hi * kLaunchCostUs[hi] + (float)(L - n_hi) * kLaunchCostUs[hi - 1];
+        if (!best_L || cost < best) {
+            best_L = L;
+            best = cost;
+        }
+    }
+    *first = best_L ? (n + best_L - 1) / best_L : 0u;
+    *n_first = best_L ? n - (*first - 1) * best_L : 0u;
+    return best_L;
+}
+
+// n substeps as the launches sbk_split_call chooses; the last launch of a call also stores strain/stress when write_aux
 void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
 {
+    uint32_t k_hi = 0, n_hi = 0;
+    sbk_split_call(n, e->bk.K, e->bk.fixed_depth, &k_hi, &n_hi);
     SbBlockedPlan bp{e->bk.d_tile_p0, e->bk.d_tile_h0, e->bk.d_halo_idx, e->bk.d_ring_cnt, e->bk.d_tile_b0, e->bk.d_tile_e0,
                      e->bk.d_tile_s0, e->bk.d_ent_word, e->bk.d_ent_state, e->bk.d_lvl_cnt, e->bk.d_tile_n0, e->bk.d_tile_nb,
                      e->bk.d_ent_length, e->d_mat, e->ntiles, e->bk.K, e->bk.cap, e->nmat, e->bk.dummy_word};
-    static const float dephase_us = [] { const char *v = getenv("SB_BK_DEPHASE_US"); return v ? (float)atof(v) : 0.0f; }();
-    static const uint32_t slots = [] { const char *v = getenv("SB_BK_SLOTS"); return v ? (uint32_t)atoi(v) : 512u; }();
-    const uint32_t dephase_lo = slots / 2, dephase_hi = slots, dephase_ticks = (uint32_t)(dephase_us * 100.0f); // 100 MHz wall clock
     while (n) {
-        const uint32_t k = n < e->bk.K ? n : e->bk.K;
+        const uint32_t k = n_hi ? k_hi : k_hi - 1u; // the deeper launches first
+        if (n_hi) n_hi--;
         const bool aux = write_aux && k == n;
         SbBlockedState bs{e->bk.d_target[e->bk.cur], e->bk.d_last[e->bk.cur], e->bk.d_target[e->bk.cur ^ 1u],
                           e->bk.d_last[e->bk.cur ^ 1u], e->beams.strain, e->beams.stress, e->d_broken};
         SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
 #define SB_LAUNCH_B(M, A)                                                                                             \
     k_substep_blocked<M, A><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,      \
-                                                                            e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1], dephase_lo, dephase_hi, dephase_ticks)
+                                                                            e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
         if (e->ntiles) {
             if (e->mat_mode == 2) {
                 if (aux) SB_LAUNCH_B(2, true); else SB_LAUNCH_B(2, false);

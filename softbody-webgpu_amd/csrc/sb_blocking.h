@@ -50,6 +50,10 @@ struct SbBlocking {
     std::vector<uint32_t> tile_n0;   // [T+1] CSR tile -> tiles that own some of its halo particles
     sbt::uvec<uint32_t> tile_nb;
     uint32_t max_region = 0, max_entries = 0, max_own = 0;
+    // per launch depth k = 1..K (index k; [0] unused): what a launch of k substeps needs and loads -- the largest region
+    // (particles of ring <= k) and entry prefix (smaller ring <= k-1) of any tile, and their totals over the tiles
+    std::vector<uint32_t> region_at, entries_at;
+    std::vector<uint64_t> sum_region_at, sum_entries_at;
 };
 
 namespace sbt {
@@ -183,21 +187,68 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     };
     std::vector<TileOut> out(T);
     sbt::parallel_tiles(T, [&](uint32_t, uint32_t k0, uint32_t k1) {
-        std::vector<uint32_t> stamp(P, 0xFFFFFFFFu), local(P, 0);
-        std::vector<uint8_t> ring(P, 0);
+        // what a tile knows about the particles of its region: local index and ring.  A small open-addressing table per
+        // worker, emptied through its own list of used cells after every tile (three scene-sized arrays per worker, filled
+        // before the first tile, were 9 bytes x P x 16 workers: 2.3 GB of host memory at 16 M particles)
+        struct RegionMap {
+            std::vector<uint32_t> key, local, used;
+            std::vector<uint8_t> ring;
+            uint32_t mask = 0;
+            explicit RegionMap(uint32_t cap = 1u << 13) { resize(cap); }
+            void resize(uint32_t cap)
+            {
+                key.assign(cap, 0xFFFFFFFFu);
+                local.assign(cap, 0u);
+                ring.assign(cap, 0);
+                mask = cap - 1u;
+            }
+            static uint32_t hash(uint32_t q) { return q * 2654435761u; }
+            // cell of q, or of the empty cell where q would go
+            uint32_t cell(uint32_t q) const
+            {
+                uint32_t c = (hash(q) >> 7) & mask;
+                while (key[c] != q && key[c] != 0xFFFFFFFFu) c = (c + 1u) & mask;
+                return c;
+            }
+            bool has(uint32_t q) const { return key[cell(q)] == q; }
+            void put(uint32_t q, uint32_t l, uint8_t r)
+            {
+                if ((used.size() + 1) * 2 > key.size()) { // half full: double
+                    std::vector<uint32_t> k2, l2;
+                    std::vector<uint8_t> r2;
+                    for (uint32_t c : used) {
+                        k2.push_back(key[c]);
+                        l2.push_back(local[c]);
+                        r2.push_back(ring[c]);
+                    }
+                    resize((uint32_t)key.size() * 2u);
+                    used.clear();
+                    for (size_t j = 0; j < k2.size(); j++) put(k2[j], l2[j], r2[j]);
+                }
+                const uint32_t c = cell(q);
+                key[c] = q;
+                local[c] = l;
+                ring[c] = r;
+                used.push_back(c);
+            }
+            void clear()
+            {
+                for (uint32_t c : used) key[c] = 0xFFFFFFFFu;
+                used.clear();
+            }
+        } reg;
         std::vector<uint32_t> frontier, next;
         struct Ent { uint64_t key; uint32_t a, slot, m; }; // key = (smaller ring, not-owned, rank): the sort order, carried along
         std::vector<Ent> ents;
         for (uint32_t k = k0; k < k1; k++) {
             TileOut &o = out[k];
             const uint32_t p0 = t.tile_p0[k], p1 = t.tile_p0[k + 1], n_own = p1 - p0;
+            reg.clear();
             frontier.clear();
-            for (uint32_t i = p0; i < p1; i++) {
-                stamp[i] = k;
-                ring[i] = 0;
-                local[i] = i - p0;
-                frontier.push_back(i);
-            }
+            for (uint32_t i = p0; i < p1; i++) frontier.push_back(i); // (own particles are told by their range, not by the table)
+            auto in_region = [&](uint32_t q) { return (q >= p0 && q < p1) || reg.has(q); };
+            auto ring_of = [&](uint32_t q) -> uint32_t { return (q >= p0 && q < p1) ? 0u : reg.ring[reg.cell(q)]; };
+            auto local_of = [&](uint32_t q) -> uint32_t { return (q >= p0 && q < p1) ? q - p0 : reg.local[reg.cell(q)]; };
             o.ring_cnt.assign(K + 1, n_own);
             o.halo.clear();
             for (uint32_t r = 1; r <= K; r++) {
@@ -205,15 +256,14 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
                 for (uint32_t p : frontier)
                     for (uint32_t e = adj0[p]; e < adj0[p + 1]; e++) {
                         const uint32_t s = adj[e], q = ba[s] == p ? bb[s] : ba[s];
-                        if (stamp[q] != k) {
-                            stamp[q] = k;
-                            ring[q] = (uint8_t)r;
+                        if (!in_region(q)) {
+                            reg.put(q, 0u, (uint8_t)r);
                             next.push_back(q);
                         }
                     }
                 std::sort(next.begin(), next.end());
                 for (uint32_t q : next) {
-                    local[q] = n_own + (uint32_t)o.halo.size();
+                    reg.local[reg.cell(q)] = n_own + (uint32_t)o.halo.size();
                     o.halo.push_back(q);
                 }
                 o.ring_cnt[r] = n_own + (uint32_t)o.halo.size();
@@ -222,15 +272,15 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
             // entries: every beam with an endpoint of ring <= K-1, once
             ents.clear();
             auto visit = [&](uint32_t p) {
-                if (ring[p] > K - 1) return;
+                if (ring_of(p) > K - 1) return;
                 for (uint32_t e = adj0[p]; e < adj0[p + 1]; e++) {
                     const uint32_t s = adj[e];
                     const uint32_t a = ba[s], b = bb[s];
                     // the beam is emitted by endpoint A, unless A lies outside the rings that emit (then by B)
-                    const bool a_emits = stamp[a] == k && ring[a] <= K - 1;
+                    const bool a_emits = in_region(a) && ring_of(a) <= K - 1;
                     if (p == a ? true : !a_emits) {
                         if (p != a && p != b) continue;
-                        const uint32_t m = std::min<uint32_t>(ring[a], ring[b]);
+                        const uint32_t m = std::min<uint32_t>(ring_of(a), ring_of(b));
                         ents.push_back(Ent{((uint64_t)m << 40) | ((uint64_t)(tile_of[a] == k ? 0u : 1u) << 32) | rank[s], a, s, m});
                     }
                 }
@@ -250,8 +300,8 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
             o.lvl_cnt.assign(K, 0);
             for (size_t j = 0; j < n; j++) {
                 const uint32_t s = ents[j].slot;
-                o.la[j] = local[ba[s]];
-                o.lb[j] = local[bb[s]];
+                o.la[j] = local_of(ba[s]);
+                o.lb[j] = local_of(bb[s]);
                 o.slot[j] = s;
                 if ((ents[j].key >> 32) & 1u) o.state.push_back(t.g_of_slot[s]);
                 for (uint32_t m = ents[j].m; m < K; m++) o.lvl_cnt[m]++;
@@ -280,6 +330,17 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
         t.max_region = std::max(t.max_region, own + (uint32_t)out[k].halo.size());
         t.max_entries = std::max(t.max_entries, (uint32_t)out[k].la.size());
     }
+    t.region_at.assign(K + 1, 0);
+    t.entries_at.assign(K + 1, 0);
+    t.sum_region_at.assign(K + 1, 0);
+    t.sum_entries_at.assign(K + 1, 0);
+    for (uint32_t k = 0; k < T; k++)
+        for (uint32_t d = 1; d <= K; d++) {
+            t.region_at[d] = std::max(t.region_at[d], out[k].ring_cnt[d]);
+            t.entries_at[d] = std::max(t.entries_at[d], out[k].lvl_cnt[d - 1]);
+            t.sum_region_at[d] += out[k].ring_cnt[d];
+            t.sum_entries_at[d] += out[k].lvl_cnt[d - 1];
+        }
     t.halo_idx.resize(t.tile_h0[T]);
     t.ring_cnt.resize((size_t)T * (K + 1));
     t.lvl_cnt.resize((size_t)T * K);

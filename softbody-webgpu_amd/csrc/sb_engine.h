@@ -37,7 +37,12 @@ struct SbParticleArrays {
 #define SB_BK_MAXP (2560 / SB_BK_T) // particles per thread  -> a region holds at most 2560 particles
 #endif
 #define SB_BK_KMAX 8u
-#define SB_BK_KDEFAULT 6u // substeps per launch when the caller does not say (1 M particles: K = 5 -> 13.8, 6 -> 13.2, 7 -> 13.4 us per substep)
+// When the caller does not say: the plan is made SB_BK_KPLAN substeps deep (if the regions fit), and a call of n substeps is
+// cut into launches of at most that depth by sbk_split_call (sb_blocked.hip), which prices the candidates with the measured
+// launch times: a long call runs at SB_BK_KLONG substeps per launch (1 M particles: 5 -> 13.8, 6 -> 13.2, 7 -> 13.4 us per
+// substep), a short one in the fewest launches (20 substeps: 7 + 7 + 6, not 6 + 6 + 6 + 2).
+#define SB_BK_KPLAN 7u
+#define SB_BK_KLONG 6u
 
 // device side of the temporally blocked plan (sb_blocking.h, sb_blocked.hip)
 struct SbBlockedDev {
@@ -50,7 +55,10 @@ struct SbBlockedDev {
              *d_tile_n0 = nullptr, *d_tile_nb = nullptr, *d_slot_e0 = nullptr, *d_slot_ent = nullptr;
     float *d_ent_length = nullptr;
     float *d_target[2] = {nullptr, nullptr}, *d_last[2] = {nullptr, nullptr};
-    uint64_t entries = 0, halo_entries = 0, halo_particles = 0; // totals, for the traffic model
+    uint32_t k_long = 0;      // substeps per launch of a long call (what the traffic model prices)
+    bool fixed_depth = false; // the caller named the depth (sb_options.block_substeps): every call runs in the fewest launches
+    uint64_t entries = 0, halo_entries = 0, halo_particles = 0; // totals of the whole plan (depth K)
+    uint64_t entries_at[SB_BK_KMAX + 1] = {}, region_at[SB_BK_KMAX + 1] = {}; // totals over the tiles of what a launch of depth k loads
 };
 
 struct sb_engine {
@@ -157,4 +165,5 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src);
 void sbk_launch_peer_exchange(sb_engine *e);
 // sb_blocked.hip
 void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux);
+uint32_t sbk_split_call(uint32_t n, uint32_t kmax, bool fewest, uint32_t *first, uint32_t *n_first); // launches: n_first of depth first, the rest first - 1
 void sbk_launch_delete_blocked(sb_engine *e);

@@ -75,6 +75,7 @@ static struct {
                                   uint32_t, float, sb_partition **);
     sb_status (*partition_destroy)(sb_partition *);
     sb_status (*partition_rank_counts)(const sb_partition *, uint32_t, uint32_t *);
+    sb_status (*partition_layout)(const sb_partition *, uint32_t *);
     sb_status (*partition_rank_scene)(const sb_partition *, uint32_t, uint32_t, uint32_t, void *, void *, void *, void *);
     sb_status (*partition_rank_ids)(const sb_partition *, uint32_t, uint32_t *, uint8_t *, uint32_t *, uint8_t *);
     sb_status (*partition_peer_counts)(const sb_partition *, uint32_t, uint32_t, uint32_t *, uint32_t *);
@@ -166,6 +167,7 @@ static napi_value js_load(napi_env env, napi_callback_info info)
     SYM(partition_create, "sb_partition_create");
     SYM(partition_destroy, "sb_partition_destroy");
     SYM(partition_rank_counts, "sb_partition_rank_counts");
+    SYM(partition_layout, "sb_partition_layout");
     SYM(partition_rank_scene, "sb_partition_rank_scene");
     SYM(partition_rank_ids, "sb_partition_rank_ids");
     SYM(partition_peer_counts, "sb_partition_peer_counts");
@@ -757,9 +759,14 @@ static napi_value js_partition_rank_scene(napi_env env, napi_callback_info info)
             napi_throw_type_error(env, NULL, "partitionRankScene: ArrayBuffer or TypedArray expected");
             return NULL;
         }
-    /* sizes: the largest record strides, so that either layout is covered by the check */
-    if (len[0] < SB_METADATA_BYTES || len[1] < ((size_t)maxp + maxb) * 2 || len[2] < (size_t)maxp * SB_PARTICLE_STRIDE ||
-        len[3] < (size_t)maxb * SB_BEAM_STRIDE_V1) {
+    /* sizes: what sb_partition_rank_scene writes follows the PARTITION's layout (2- or 4-byte mapping indices, 40- or 44-byte
+     * beam records), not what the caller may have assumed: buffers sized for v1 handed in for a v2 partition are refused here
+     * instead of being overrun */
+    uint32_t layout = 0;
+    if (sb.partition_layout(pt, &layout) != SB_OK) return throw_status(env, NULL, SB_ERR_INVALID, "sb_partition_layout");
+    const size_t isz = layout == SB_LAYOUT_V1 ? 2 : 4, bstride = layout == SB_LAYOUT_V1 ? SB_BEAM_STRIDE_V1 : SB_BEAM_STRIDE_V2;
+    if (len[0] < SB_METADATA_BYTES || len[1] < ((size_t)maxp + maxb) * isz || len[2] < (size_t)maxp * SB_PARTICLE_STRIDE ||
+        len[3] < (size_t)maxb * bstride) {
         napi_throw_range_error(env, NULL, "partitionRankScene: a buffer is smaller than the capacities say");
         return NULL;
     }

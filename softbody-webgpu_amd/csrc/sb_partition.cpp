@@ -282,6 +282,13 @@ sb_status sb_partition_rank_counts(const sb_partition *p, uint32_t rank, uint32_
     return SB_OK;
 }
 
+sb_status sb_partition_layout(const sb_partition *p, uint32_t *layout)
+{
+    if (!p || !layout) return SB_ERR_INVALID;
+    *layout = p->layout;
+    return SB_OK;
+}
+
 sb_status sb_partition_rank_scene(const sb_partition *p, uint32_t rank, uint32_t max_particles, uint32_t max_beams, void *metadata,
                                   void *mapping, void *particles, void *beams)
 {

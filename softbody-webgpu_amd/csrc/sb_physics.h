@@ -65,6 +65,13 @@ SB_DEV float sb_length(float x, float y) { return sb_sqrt(x * x + y * y); }
 //   1/x : y = v_rcp_f32(x); y' = fma(y, fma(-x, y, 1), y)                          2^-45 <= x <= 2^45
 // (the reciprocal gate holds every sqrt the sqrt gate can return).  Callers test the gate for the whole wave and take
 // the IEEE sequences otherwise, so zero, subnormal, huge, infinite and NaN operands never reach the short forms.
+// "Exhaustively checked" is a statement about ONE instruction set: v_rsq_f32 / v_rcp_f32 are only ULP-bounded by the ISA, and
+// another target's tables may differ.  A device build for anything but gfx950 therefore stops here instead of silently
+// resting every bit-exact guarantee on unverified sequences (run tools/exact_math_check.hip on the new target, commit its
+// log under profiles/, then add the target to this list).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "sb_sqrt_gated / sb_rcp_gated are verified bit-exact on gfx950 only (profiles/r02_exact_math_check.txt)"
+#endif
 SB_DEV bool sb_in_sqrt_gate(float x) { return x >= 0x1p-90f && x <= 0x1p90f; } // false for NaN
 SB_DEV float sb_sqrt_gated(float x)
 {

@@ -102,6 +102,7 @@ def load_library():
     L.sb_partition_create.argtypes = [u32, u32, u32, vp, vp, vp, vp, u32, u32, f32, ctypes.POINTER(vp)]
     L.sb_partition_destroy.argtypes = [vp]
     L.sb_partition_rank_counts.argtypes = [vp, u32, ctypes.POINTER(u32 * 8)]
+    L.sb_partition_layout.argtypes = [vp, ctypes.POINTER(u32)]
     L.sb_partition_rank_scene.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp]
     L.sb_partition_rank_ids.argtypes = [vp, u32, vp, vp, vp, vp]
     L.sb_partition_peer_counts.argtypes = [vp, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32 * 4)]

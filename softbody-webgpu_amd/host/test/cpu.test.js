@@ -155,6 +155,20 @@ const same = (ab, file) => Buffer.compare(Buffer.from(ab), fs.readFileSync(path.
         }
         assert.throws(() => h.partitionScene(m, 2, 0, 0), /depth 0/);
         const a = h.native();
+        {
+            // buffers sized for the v1 records (2-byte indices, 40-byte beams) handed in for a v2 partition: sb_partition_rank_scene
+            // would write 4-byte indices and 44-byte beams past their ends, so the addon refuses them by the PARTITION's layout
+            const part = a.partitionCreate(2, m.maxParticles, m.maxBeams, m.metadata, m.mapping, m.particleData, m.beamData, 2, 2, 0);
+            try {
+                const c = a.partitionRankCounts(part, 0), P = Math.max(c[0], 1), B = Math.max(c[1], 1);
+                const md = new ArrayBuffer(112), pd = new ArrayBuffer(24 * P);
+                assert.throws(() => a.partitionRankScene(part, 0, P, B, md, new ArrayBuffer(2 * (P + B)), pd, new ArrayBuffer(44 * B)), RangeError);
+                assert.throws(() => a.partitionRankScene(part, 0, P, B, md, new ArrayBuffer(4 * (P + B)), pd, new ArrayBuffer(40 * B)), RangeError);
+                a.partitionRankScene(part, 0, P, B, md, new ArrayBuffer(4 * (P + B)), pd, new ArrayBuffer(44 * B));
+            } finally {
+                a.partitionDestroy(part);
+            }
+        }
         for (const f of ['haloConfigure', 'haloSetLayout', 'peerMailbox', 'peerMap', 'peerConnect', 'peerExchange', 'getStream'])
             assert.strictEqual(typeof a[f], 'function', f);
     });
