@@ -11,8 +11,14 @@ resident in HBM when the timed region starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline`, `cpu_baseline` and, at N=1, `extra`
-(BASELINE config 3 measured in the same run, upload / read-back times).
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline`, `cpu_baseline` (at every N) and `extra`:
+at N=1 the single-substep kernel, BASELINE config 3, a steady-state figure (960 substeps after 64) and one GPU's share of
+configs 4 and 5; at N>1 configs 4 (N slabs of 500 x 4000) and 5 (N slabs of 1000 x 8000, mixed stiffness, dt 1/128)
+measured in the same run.  `--config4` / `--config5` make those shapes the main workload.
+
+N>1: every rank times its own substep launches and ghost refreshes with HIP events on its engine's stream (sb_mark), the
+timed region starts on a refresh boundary and holds at least one refresh whatever --steps is (the ghost depth is lowered to
+a divisor of --steps when the region is shorter than four refresh periods), and the line says how many there were.
 """
 import argparse
 import json
@@ -32,8 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--width", type=int, default=1000, help="lattice columns per GPU")
-    ap.add_argument("--height", type=int, default=1000, help="lattice rows")
+    ap.add_argument("--width", type=int, default=None, help="lattice columns per GPU (default 1000)")
+    ap.add_argument("--height", type=int, default=None, help="lattice rows (default 1000)")
     ap.add_argument("--collisions", choices=["off", "grid"], default="off")
     ap.add_argument("--spacing", type=float, default=30.0, help="lattice spacing d (particle radius is 10)")
     ap.add_argument("--origin-y", type=float, default=1000.0, help="y of the lattice's bottom row (10 = resting on the floor)")
@@ -50,7 +56,7 @@ def parse():
                     help="collisions off: substeps per launch of the temporally blocked kernel (0 = engine default, 1 = off)")
     ap.add_argument("--ghost-depth", type=int, default=30,
                     help="N>1: ghost-zone depth in lattice columns = substeps between halo exchanges")
-    ap.add_argument("--subticks", type=int, default=64)
+    ap.add_argument("--subticks", type=int, default=None, help="default 64 (128 with --config5)")
     ap.add_argument("--soup", action="store_true",
                     help="config 3 with EVERY mechanism acting: width x height FREE particles (no beams) on a grid of "
                          "--spacing (default here 40) jittered by +-10, thrown around at up to --soup-speed units/s: "
@@ -68,7 +74,14 @@ def parse():
                     help="N>1 on a single-GPU box: every rank uses cuda:0 and the process group is gloo (control "
                          "plane only), so the multi-rank code path and the peer exchange can be exercised; not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 record of `extra`")
+    ap.add_argument("--no-extra", action="store_true", help="skip the records of `extra`")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE config 4 as the main workload: one 500 x 4000 slab per GPU (8 GPUs: the 4000 x 4000 lattice, "
+                         "16 M particles), ghost-halo exchange between neighbours")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE config 5 as the main workload: one 1000 x 8000 slab per GPU (8 GPUs: 64 M particles), springs "
+                         "drawn from {1,3,50,500}, subticks 128")
+    ap.add_argument("--steady-steps", type=int, default=960, help="N=1: substeps of extra.steady_state (after 64 of warm-up)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
 
@@ -271,11 +284,14 @@ def peer_exchanger(halo, eng, plan, buf, dist, torch, ctl):
 
 
 def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
-    """`achieved` = the launched kernels' own compulsory HBM bytes per substep (sb_get_info "substep_hbm_bytes":
-    every array element the substep has to read or write with the data layout the engine holds) / HIP-event time
-    per substep; a fraction of the 8 TB/s peak that is <= 1 by construction and that the PMC bytes under `traffic`
-    must reproduce.  The reference-layout figure of SURVEY.md 8(d) (52 B per beam + 48 B per particle) is reported
-    beside it as an equivalent rate, clearly not a fraction: this kernel does not move those bytes."""
+    """`achieved` = the ALGORITHMIC bytes of the launched kernel per substep -- its own compulsory HBM traffic, every array
+    element the substep has to read or write with the data layout the engine holds (sb_get_info "substep_hbm_bytes") -- / the
+    HIP-event time per substep, as a fraction of the 8 TB/s peak.  `traffic` is what the PMC counters of the committed profile
+    measured per launch: equal to the model for the single-substep kernel; BELOW it for the blocked kernel (halo lines that
+    several tiles gather are charged to each of them by the model and served once from HBM, then by L2), so the object also
+    carries `achieved_measured` / `frac_measured`, priced with the measured bytes.  The blocked kernel is not bound by HBM
+    but by instruction issue: `binding_roof` says so and `valu_issue` holds that fraction.  The reference-layout figure of
+    SURVEY.md 8(d) (52 B per beam + 48 B per particle) is an equivalent rate, not a fraction: no kernel here moves those bytes."""
     per_substep_s = kernel_ms * 1e-3 / steps
     own = float(eng.info("substep_hbm_bytes"))
     k = max(1, eng.info("substeps_per_launch"))
@@ -286,18 +302,23 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
             "kernel": eng.kernel_name() if tiled else "k_beams_atomic+k_particles",
             "substeps_per_launch": k, "avg_launch_us": per_substep_s * k * 1e6,
             "compulsory_bytes_per_launch": own * k,
+            "binding_roof": "valu_issue" if k > 1 else "hbm",
             "reference_layout_bytes_per_substep": 52.0 * B_local + 48.0 * P_local,
             "reference_layout_equiv_GBps": (52.0 * B_local + 48.0 * P_local) / per_substep_s / 1e9,
             "note": "achieved = compulsory bytes of the launched kernel (engine's own data layout: %d beam copies for %d "
-                    "beams, material mode %d) / HIP-event time of the timed region; reference_layout_equiv_GBps = "
-                    "(52*B + 48*P) / the same time is what a kernel streaming the reference's records would need to "
-                    "sustain for this step rate -- an equivalence, not a fraction of the roof"
-                    % (eng.info("beam_copies"), B_local, eng.info("material_mode"))}
+                    "beams, material mode %d, %d substeps per launch of a long call, plan depth %d) / HIP-event time of the "
+                    "substep launches of the timed region (a short call is cut into balanced launches, which may be deeper "
+                    "than a long call's); reference_layout_equiv_GBps = (52*B + 48*P) / the same time is what a kernel "
+                    "streaming the reference's records would need to sustain for this step rate -- an equivalence, not a "
+                    "fraction of the roof"
+                    % (eng.info("beam_copies"), B_local, eng.info("material_mode"), k, eng.info("plan_depth"))}
     tr = committed_traffic(workload, roof["kernel"].split("<")[0])
     if tr:
         roof["traffic"] = tr[0]
         roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command)" % tr[1]
         roof["traffic_over_compulsory"] = tr[0] / (own * k)
+        roof["achieved_measured"] = tr[0] / (per_substep_s * k) / 1e9
+        roof["frac_measured"] = roof["achieved_measured"] / HBM_PEAK_GBS
     if k > 1:
         # the temporally blocked kernel is bound by instruction issue, not by HBM: the second roof it is
         # measured against.  1024 SIMDs issue one wave64 fp32 instruction per 2.8 cycles with four waves each (tools/valu_rate.hip)
@@ -307,7 +328,7 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
             roof["valu_issue"] = {"insts_per_launch": va[0], "source": "profiles/%s sq_counters (SQ_INSTS_VALU)" % va[1],
                                   "frac_of_issue_peak": va[0] * cycles_per_inst / (simds * clock_hz * per_substep_s * k),
                                   "note": "wave instructions x 2.8 cycles / (1024 SIMDs x 2.4 GHz x launch time); the launch's "
-                                          "load/store phase (about a third of it) issues almost nothing"}
+                                          "load/store phase issues almost nothing"}
     return roof
 
 
@@ -335,6 +356,30 @@ def measure_single_substep(sb, a, buf, bounds, workload):
     return rec
 
 
+def measure_steady_state(sb, a, buf, bounds, mode):
+    """The main workload once more at the step counts DESIGN.md quotes (default 960 substeps after 64 of warm-up), so that
+    the driver's own record holds the steady-state rate beside the one its short protocol gives.  Never `value`."""
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2, max_particles=buf.max_particles,
+                    max_beams=buf.max_beams, collision_mode=mode, block_substeps=a.block_substeps, grid_skin=a.grid_skin)
+    eng.write_buffers(buf)
+    eng.step(64)
+    eng.sync()
+    t0 = time.perf_counter()
+    ms = eng.step_timed(a.steady_steps)
+    eng.sync()
+    wall = time.perf_counter() - t0
+    own = float(eng.info("substep_hbm_bytes"))
+    per = ms * 1e-3 / a.steady_steps
+    rec = {"steps": a.steady_steps, "warmup": 64, "kernel": eng.kernel_name(),
+           "value": buf.particle_count * a.steady_steps / wall, "value_by_device_time": buf.particle_count / per,
+           "unit": "particle-steps/s", "us_per_substep": per * 1e6, "substeps_per_launch": eng.info("substeps_per_launch"),
+           "compulsory_GBps": own / per / 1e9, "frac_of_hbm_peak": own / per / 1e9 / HBM_PEAK_GBS,
+           "note": "same scene and engine options as the driver line, %d substeps after 64: the rate a long run sustains "
+                   "(the driver's protocol times %d substeps after %d)" % (a.steady_steps, a.steps, a.warmup)}
+    eng.destroy()
+    return rec
+
+
 def measure_config3(sb, a):
     """BASELINE config 3 in the same run (rank 0, N=1): the blob pile, spatial-hash collisions, same step counts."""
     import numpy as np
@@ -354,6 +399,12 @@ def measure_config3(sb, a):
     ms = eng.step_timed(a.steps)
     eng.sync()
     builds = eng.info("grid_builds") - builds0
+    steady = None
+    if a.steady_steps > a.steps:                        # ... and at the step counts DESIGN.md quotes (never `value`)
+        b0 = eng.info("grid_builds")
+        ms2 = eng.step_timed(a.steady_steps)
+        steady = {"steps": a.steady_steps, "value": buf.particle_count * a.steady_steps / (ms2 * 1e-3),
+                  "us_per_substep": ms2 * 1e3 / a.steady_steps, "grid_builds": eng.info("grid_builds") - b0}
     out = eng.load_buffers(buf.copy())
     eng.destroy()
     P = buf.particle_count
@@ -362,7 +413,7 @@ def measure_config3(sb, a):
            "value": P * a.steps / (ms * 1e-3), "unit": "particle-steps/s", "us_per_substep": ms * 1e3 / a.steps,
            "steps": a.steps, "warmup": a.warmup, "grid_builds": builds, "upload_ms": upload_ms,
            "finite": bool(np.isfinite(out.particles[:P]).all()), "max_speed": float(v.max()),
-           "beams_left": out.beam_count,
+           "beams_left": out.beam_count, "steady_state": steady,
            "contacts": "tools/config3_contacts_check.py measures the share of particles the collision loop changes "
                        "(profiles/r02_config3_contacts_check.txt)"}
     # measured HBM bytes per substep of the two kernels of this scene, from the committed PMC passes of `bench.py --config3`
@@ -372,94 +423,62 @@ def measure_config3(sb, a):
         rec["hbm"] = {"traffic_bytes_per_substep": per_substep, "achieved_GBps": per_substep / (ms * 1e-3 / a.steps) / 1e9,
                       "frac_of_peak": per_substep / (ms * 1e-3 / a.steps) / 1e9 / HBM_PEAK_GBS,
                       "source": "profiles/%s traffic_config3 (k_substep_tiled_grid + k_grid_maintain, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tr[0][1],
-                      "note": "neighbour lists and position gathers included; the substep kernel alone moves 131 MB in ~26 us on the "
-                              "substeps that do not rebuild the hash (5 TB/s)"}
+                      "note": "neighbour lists and position gathers included; %.0f MB per launch of the substep kernel, %.1f MB per "
+                              "launch of the hash helper (averages over the launches of the profiled run)"
+                              % (tr[0][0] / 1e6, tr[1][0] / 1e6)}
     if not a.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline_config3(sb, settled, bounds, a.cpu_seconds)
     return rec
 
 
-def main():
-    a = parse()
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        sys.exit(spawn_ranks(a))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    a.gpus = world
-    import torch
-    import __graft_entry__ as ge
-    sb = ge.load_package()
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
-    if a.rehearse_one_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dist = None
-    ctl = "cpu" if a.rehearse_one_gpu else "cuda"      # where the few control-plane tensors live
-    if world > 1:
-        import torch.distributed as dist
-        if a.rehearse_one_gpu:
-            dist.init_process_group("gloo")
-            a.exchange = "peer"
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+def effective_depth(want, steps, width):
+    """Substeps between ghost refreshes = ghost-zone depth in columns.  A timed region of at least four refresh periods takes
+    the depth asked for; a shorter one (the driver times 20 substeps) takes the largest depth <= the one asked for that
+    DIVIDES --steps, so that the region -- which starts on a refresh boundary -- holds whole refresh periods and ends on a
+    refresh: steps / depth exchanges are inside it, never zero."""
+    d = max(1, min(want, width))
+    if steps >= 4 * d:
+        return d
+    for c in range(min(d, max(steps, 1)), 0, -1):
+        if steps % c == 0:
+            return c
+    return 1
 
-    from importlib import import_module
-    halo = import_module("softbody_webgpu_amd.halo") if world > 1 else None
 
-    if a.lattice_on_floor:
-        a.width, a.height, a.spacing, a.origin_y, a.collisions = 4000, 250, 22.0, 10.0, "grid"
-    if a.soup:
-        a.collisions = "grid"
-        if a.spacing == 30.0:
-            a.spacing = 40.0
-        if a.origin_y == 1000.0:
-            a.origin_y = 30.0       # bottom rows within reach of the floor
-    if a.config3:
-        a.collisions = "grid"
-    W, H = a.width, a.height
+class Ctx:
+    pass
+
+
+def run_workload(ctx, a, W, H, subticks, mixed, mode, steps, warmup, named=None, want_cpu=True, cpu_seconds=None,
+                 readback=False):
+    """One lattice workload on every rank: scene -> engine -> exchanger -> warm-up -> timed region -> verify.  All ranks
+    call it together; returns the record (rank 0 fills it in, the others get the shared numbers too)."""
+    sb, halo, torch, dist = ctx.sb, ctx.halo, ctx.torch, ctx.dist
+    rank, world, local, ctl = ctx.rank, ctx.world, ctx.local, ctx.ctl
     d = a.spacing
-    mode = {"off": 0, "grid": 2}[a.collisions]
-    path = {"auto": 0, "atomic": 1, "tiled": 2}[a.path]
-    # global scene: N slabs of W columns side by side (weak scaling: per-GPU work is fixed)
-    bounds = float(max(W * world, H) * d + 2000.0)
-    if a.soup or a.config3:
-        if world != 1:
-            sys.exit("--soup / --config3 are single-GPU scenes")
-        if a.soup:
-            buf = sb.scenes.soup_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=10.0, speed=a.soup_speed)
-        else:
-            buf, bounds = sb.scenes.config3_buffers()
-        plan = None
-    elif world == 1:
+    bounds = float(max(W * world, H) * d + 2000.0)   # global scene: N slabs of W columns side by side (weak scaling)
+    depth = effective_depth(a.ghost_depth, steps, W) if world > 1 else 0
+    if world == 1:
         buf = sb.scenes.lattice_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0, layout=2)
         plan = None
     else:
-        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0,
-                                    depth=a.ghost_depth)
-    if a.mixed_stiffness:
+        buf, plan = halo.slab_scene(sb, rank, world, W, H, d=d, origin=(1000.0, a.origin_y), jitter=1.0, depth=depth)
+    if mixed:
         if plan is not None:
-            halo.mix_stiffness(buf, plan, subticks=a.subticks)   # keyed by global beam id: ghosts match their owners
+            halo.mix_stiffness(buf, plan, subticks=subticks)   # keyed by global beam id: ghosts match their owners
         else:
-            sb.scenes.mix_stiffness(buf, subticks=a.subticks)
+            sb.scenes.mix_stiffness(buf, subticks=subticks)
     P_local = buf.particle_count if plan is None else plan.n_owned
     B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
-    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2,
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=subticks, layout=2,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
-                    path=path, tile_particles=a.tile, device=local, grid_skin=a.grid_skin,
-                    block_substeps=a.block_substeps)
+                    path={"auto": 0, "atomic": 1, "tiled": 2}[a.path], tile_particles=a.tile, device=local,
+                    grid_skin=a.grid_skin, block_substeps=a.block_substeps)
     t0 = time.perf_counter()
     eng.write_buffers(buf)
     upload_ms = (time.perf_counter() - t0) * 1e3
-    if a.config3:
-        for _ in range(sb.scenes.CONFIG3_SETTLE_FRAMES):   # the pile comes to rest on itself (untimed)
-            eng.frame()
-        eng.sync()
-    exchange_mode = None
-    if plan is None:
-        stepper = eng.step
-    else:
+    exchange_mode, transport, ex = None, None, None
+    if plan is not None:
         ex = peer_exchanger(halo, eng, plan, buf, dist, torch, ctl) if a.exchange == "peer" else None
         if ex is not None:
             exchange_mode = "direct stores into the neighbours' IPC-mapped mailboxes, flag handshake on the engine stream"
@@ -472,7 +491,6 @@ def main():
             transport = halo.TorchTransport(torch, dist, torch.device("cuda", local), eng.stream(),
                                             ordered=a.exchange != "sync")
             ex = halo.Exchanger(eng, plan, transport)
-        stepper = ex.step
 
     def barrier():
         eng.sync()                 # the engine runs on its own HIP stream
@@ -481,83 +499,240 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    stepper(a.warmup)
+    timer = halo.StepTimer(eng)
+    if ex is None:
+        eng.step(warmup)
+    else:
+        ex.step(warmup)
+        ex.refresh_now()           # untimed: the timed region starts on a refresh boundary, the next refresh is `depth` substeps in
+        ex.exchanges = 0
+        ex.timer = timer
     barrier()
     t0 = time.perf_counter()
-    if plan is None:
-        kernel_ms = eng.step_timed(a.steps)   # HIP events on the engine's own stream
+    if ex is None:
+        timer.run("step", eng.step, steps)   # HIP events on the engine's own stream, no wait
     else:
-        stepper(a.steps)
-        kernel_ms = None
+        ex.step(steps)
     barrier()
     wall = time.perf_counter() - t0
-    if plan is not None:
-        ex.verify()       # refuses a halo run in which beams broke (break flags do not cross ranks)
+    tot = timer.totals()
+    kernel_ms = tot.get("step", (0, 0.0))[1]
+    n_exch, exch_ms = tot.get("exchange", (0, 0.0))
+    if ex is not None:
+        ex.timer = None
+        ex.verify()       # refuses a halo run in which beams were removed outside Exchanger.frame()
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=ctl)
+        t = torch.tensor([wall, kernel_ms, exch_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        wall, kernel_ms, exch_ms = (float(x) for x in t.tolist())
         cnt = torch.tensor([P_local], dtype=torch.float64, device=ctl)
         dist.all_reduce(cnt)
         P_total = int(cnt.item())
     else:
         P_total = P_local
+    placed = "" if (d == 30.0 and a.origin_y == 1000.0) else ", spacing %g, bottom row at y=%g" % (d, a.origin_y)
+    if a.lattice_on_floor:
+        placed += " (resting on the floor: floor response active, 8 collision candidates per particle tested " \
+                  "every substep, none closer than 2r in the timed window)"
+    cfg = named or ("3" if mode == 2 else "2")
+    workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
+                "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
+                % (cfg, W, H, P_local, B_local,
+                   "springs {1,3,50,500} (config 5 mix)" if mixed else "spring 50 damp 700",
+                   subticks, {0: "off", 2: "grid"}[mode], placed))
+    rec = {"value": P_total * steps / wall, "unit": "particle-steps/s", "ms_per_step": wall * 1e3 / steps,
+           "steps": steps, "warmup": warmup, "n_gpus": world, "workload": workload, "particles_total": P_total,
+           "path": {1: "atomic", 2: "tiled"}[eng.info("path")], "tiles": eng.info("tiles"),
+           "grid_builds": eng.info("grid_builds") if mode == 2 else None, "upload_ms": upload_ms,
+           "kernel_us_per_substep": kernel_ms * 1e3 / steps,
+           "roofline": roofline(eng, kernel_ms, steps, P_local, B_local, workload) if kernel_ms > 0 else None}
+    if world == 1:
+        rec["parallelism"] = "single GPU"
+    else:
+        rec["parallelism"] = ("%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, ghost p,v,a + "
+                              "beam target/last refreshed every %d substeps (%s)"
+                              % (world, W, depth, depth, exchange_mode or "RCCL neighbour send/recv, " + transport.mode))
+        rec["exchange"] = {"ghost_depth": depth, "ghost_depth_asked": a.ghost_depth,
+                           "exchanges_in_timed_region": ex.exchanges,
+                           "exchange_us_avg": (exch_ms * 1e3 / n_exch) if n_exch else None,
+                           "exchange_share_of_device_time": exch_ms / (exch_ms + kernel_ms) if (exch_ms + kernel_ms) > 0 else None,
+                           "transport": "peer" if exchange_mode else "rccl (" + transport.mode + ")",
+                           "note": "device time of sb_peer_exchange (pack into the neighbours' mailboxes, flag handshake, unpack) "
+                                   "or of pack + RCCL send/recv + unpack, HIP events on each rank's engine stream, max over ranks; "
+                                   "the timed region starts on a refresh boundary"}
+    if readback and world == 1:
+        out = buf.copy()                       # (the destination; its allocation is not the engine's time)
+        t0 = time.perf_counter()
+        eng.load_buffers(out)
+        rec["readback_ms"] = (time.perf_counter() - t0) * 1e3
+    eng.destroy()
+    rec["cpu_baseline"] = None
+    if want_cpu and rank == 0 and not a.no_cpu_baseline:
+        cb = cpu_baseline(buf, bounds, mode, cpu_seconds or a.cpu_seconds, subticks)
+        if world > 1:
+            cb["sample"] = ("rank 0's slab only -- ONE GPU's share of the scene, its %d ghost columns included (%d particles); "
+                            % (depth, buf.particle_count)) + cb["sample"]
+            cb["share"] = "per-GPU share (1 of %d slabs)" % world
+        rec["cpu_baseline"] = cb
+    rec["_buf"], rec["_bounds"] = buf, bounds
+    if dist is not None:
+        dist.barrier()
+    return rec
 
-    if rank == 0:
-        if a.soup:
-            workload = ("BASELINE config 3 as a particle soup: %dx%d FREE particles (no beams) on a grid of %g jittered "
-                        "by +-10, velocities up to %g units/s, gravity, floor and walls, spatial-hash collisions, "
-                        "subticks %d, v2 (u32) layout" % (W, H, d, a.soup_speed, a.subticks))
-        elif a.config3:
-            workload = sb.scenes.CONFIG3_TEXT % (P_local, B_local, bounds)
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
+    ctx = Ctx()
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    a.gpus = world
+    import torch
+    import __graft_entry__ as ge
+    ctx.torch = torch
+    ctx.sb = sb = ge.load_package()
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if a.rehearse_one_gpu:
+        local = 0
+    ctx.local = local
+    torch.cuda.set_device(local)
+    ctx.dist = dist = None
+    ctx.ctl = "cpu" if a.rehearse_one_gpu else "cuda"      # where the few control-plane tensors live
+    if world > 1:
+        import torch.distributed as dist
+        ctx.dist = dist
+        if a.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+            a.exchange = "peer"
         else:
-            placed = "" if (d == 30.0 and a.origin_y == 1000.0) else ", spacing %g, bottom row at y=%g" % (d, a.origin_y)
-            if a.lattice_on_floor:
-                placed += " (resting on the floor: floor response active, 8 collision candidates per particle tested " \
-                          "every substep, none closer than 2r in the timed window)"
-            workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
-                        "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
-                        % ("3" if mode == 2 else "2", W, H, P_local, B_local,
-                           "springs {1,3,50,500} (config 5 mix)" if a.mixed_stiffness else "spring 50 damp 700",
-                           a.subticks, a.collisions, placed))
-        roof = roofline(eng, kernel_ms, a.steps, P_local, B_local, workload) if kernel_ms is not None else None
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from importlib import import_module
+    ctx.halo = import_module("softbody_webgpu_amd.halo")
+
+    shaped = a.width is not None or a.height is not None or a.subticks is not None   # an explicit shape: no config-4/5 extras
+    named = None
+    if a.config4:
+        a.width, a.height, named = a.width or 500, a.height or 4000, "4 (one slab of the 4000-row lattice per GPU)"
+    if a.config5:
+        a.width, a.height, a.subticks, a.mixed_stiffness = a.width or 1000, a.height or 8000, a.subticks or 128, True
+        named = "5 (one slab of the 8000-row lattice per GPU)"
+    a.width, a.height, a.subticks = a.width or 1000, a.height or 1000, a.subticks or 64
+    if a.lattice_on_floor:
+        a.width, a.height, a.spacing, a.origin_y, a.collisions = 4000, 250, 22.0, 10.0, "grid"
+    if a.soup:
+        a.collisions = "grid"
+        if a.spacing == 30.0:
+            a.spacing = 40.0
+        if a.origin_y == 1000.0:
+            a.origin_y = 30.0       # bottom rows within reach of the floor
+    if a.config3:
+        a.collisions = "grid"
+    mode = {"off": 0, "grid": 2}[a.collisions]
+
+    if a.soup or a.config3:
+        line = special_scene(ctx, a, mode)
+    else:
+        rec = run_workload(ctx, a, a.width, a.height, a.subticks, a.mixed_stiffness, mode, a.steps, a.warmup, named=named,
+                           readback=True)
+        buf, bounds = rec.pop("_buf"), rec.pop("_bounds")
         line = {
-            "metric": "particle-steps/sec", "value": P_total * a.steps / wall, "unit": "particle-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
+            "metric": "particle-steps/sec", "value": rec["value"], "unit": "particle-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not a.rehearse_one_gpu else "synthetic; REHEARSAL: all ranks share one GPU, not a measurement",
-            "config": {"workload": workload,
-                       "particles_total": P_total, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
-                       "tiles": eng.info("tiles"), "grid_builds": eng.info("grid_builds") if mode == 2 else None,
-                       "parallelism": "single GPU" if world == 1 else
-                       "%d x-slabs of %d columns, ghost zones %d columns deep stepped redundantly, ghost p,v,a + "
-                       "beam target/last refreshed every %d substeps (%s)"
-                       % (world, W, a.ghost_depth, a.ghost_depth,
-                          exchange_mode or "RCCL neighbour send/recv, " + transport.mode)},
-            "roofline": roof,
+            "config": {"workload": rec["workload"], "particles_total": rec["particles_total"], "path": rec["path"],
+                       "tiles": rec["tiles"], "grid_builds": rec["grid_builds"], "parallelism": rec["parallelism"],
+                       "kernel_us_per_substep": rec["kernel_us_per_substep"]},
+            "roofline": rec["roofline"], "cpu_baseline": rec["cpu_baseline"],
         }
+        if "exchange" in rec:
+            line["config"]["exchange"] = rec["exchange"]
+        extra = {}
         if world == 1:
-            out = buf.copy()                       # (the destination; its allocation is not the engine's time)
-            t0 = time.perf_counter()
-            eng.load_buffers(out)
-            readback_ms = (time.perf_counter() - t0) * 1e3
-            line["extra"] = {"upload_ms": upload_ms, "readback_ms": readback_ms,
-                             "upload_note": "sb_write_buffers / sb_load_buffers of the whole scene, host buffers <-> HBM, "
-                                            "tiling and AoS<->SoA transposes included; never part of `value`"}
-    eng.destroy()
+            extra.update({"upload_ms": rec["upload_ms"], "readback_ms": rec.get("readback_ms"),
+                          "upload_note": "sb_write_buffers / sb_load_buffers of the whole scene, host buffers <-> HBM, "
+                                         "tiling and AoS<->SoA transposes included; never part of `value`"})
+        if not a.no_extra:
+            plain = not (named or shaped or a.mixed_stiffness or a.lattice_on_floor)
+            if world == 1 and rank == 0:
+                if mode == 0 and line["roofline"] and line["roofline"]["substeps_per_launch"] > 1:
+                    extra["single_substep_kernel"] = measure_single_substep(sb, a, buf, bounds, rec["workload"])
+                extra["steady_state"] = measure_steady_state(sb, a, buf, bounds, mode)
+                if plain:
+                    extra["config3"] = measure_config3(sb, a)
+            del buf
+            if plain and mode == 0:
+                # BASELINE configs 4 and 5 in the same run: at N GPUs, N slabs of each (at 8 GPUs these ARE configs 4 and 5;
+                # below that, N GPUs' share of them), same step counts, their own exchanges, a short CPU baseline
+                for key, (W, H, st, mix, nm) in (("config4", (500, 4000, 64, False, "4 (one slab of the 4000-row lattice per GPU)")),
+                                                 ("config5", (1000, 8000, 128, True, "5 (one slab of the 8000-row lattice per GPU)"))):
+                    r = run_workload(ctx, a, W, H, st, mix, 0, a.steps, a.warmup, named=nm, cpu_seconds=4.0)
+                    r.pop("_buf"), r.pop("_bounds")
+                    r["share_of_config"] = "%d of 8 slabs" % world
+                    extra[key if world > 1 else key + "_share"] = r
+        if extra:
+            line["extra"] = extra
     if rank == 0:
-        if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(buf, bounds, mode, a.cpu_seconds, a.subticks)
-        else:
-            line["cpu_baseline"] = None
-        if world == 1 and not a.no_extra and not (a.config3 or a.soup):
-            if mode == 0 and line["roofline"] and line["roofline"]["substeps_per_launch"] > 1:
-                line["extra"]["single_substep_kernel"] = measure_single_substep(sb, a, buf, bounds, workload)
-            line["extra"]["config3"] = measure_config3(sb, a)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def special_scene(ctx, a, mode):
+    """--soup / --config3 as the main workload (single GPU): scenes that are not one lattice per GPU."""
+    sb = ctx.sb
+    if ctx.world != 1:
+        sys.exit("--soup / --config3 are single-GPU scenes")
+    W, H, d = a.width, a.height, a.spacing
+    bounds = float(max(W, H) * d + 2000.0)
+    if a.soup:
+        buf = sb.scenes.soup_buffers(W, H, d=d, origin=(1000.0, a.origin_y), jitter=10.0, speed=a.soup_speed)
+    else:
+        buf, bounds = sb.scenes.config3_buffers()
+    P, B = buf.particle_count, buf.beam_count
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2,
+                    max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
+                    path={"auto": 0, "atomic": 1, "tiled": 2}[a.path], tile_particles=a.tile, device=ctx.local,
+                    grid_skin=a.grid_skin, block_substeps=a.block_substeps)
+    t0 = time.perf_counter()
+    eng.write_buffers(buf)
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    if a.config3:
+        for _ in range(sb.scenes.CONFIG3_SETTLE_FRAMES):   # the pile comes to rest on itself (untimed)
+            eng.frame()
+        eng.sync()
+    eng.step(a.warmup)
+    eng.sync()
+    ctx.torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = eng.step_timed(a.steps)
+    eng.sync()
+    wall = time.perf_counter() - t0
+    if a.soup:
+        workload = ("BASELINE config 3 as a particle soup: %dx%d FREE particles (no beams) on a grid of %g jittered "
+                    "by +-10, velocities up to %g units/s, gravity, floor and walls, spatial-hash collisions, "
+                    "subticks %d, v2 (u32) layout" % (W, H, d, a.soup_speed, a.subticks))
+    else:
+        workload = sb.scenes.CONFIG3_TEXT % (P, B, bounds)
+    line = {
+        "metric": "particle-steps/sec", "value": P * a.steps / wall, "unit": "particle-steps/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "particles_total": P, "path": {1: "atomic", 2: "tiled"}[eng.info("path")],
+                   "tiles": eng.info("tiles"), "grid_builds": eng.info("grid_builds"), "parallelism": "single GPU"},
+        "roofline": roofline(eng, kernel_ms, a.steps, P, B, workload),
+    }
+    out = buf.copy()
+    t0 = time.perf_counter()
+    eng.load_buffers(out)
+    line["extra"] = {"upload_ms": upload_ms, "readback_ms": (time.perf_counter() - t0) * 1e3}
+    eng.destroy()
+    line["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline(buf, bounds, mode, a.cpu_seconds, a.subticks)
+    return line
 
 
 if __name__ == "__main__":

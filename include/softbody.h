@@ -142,6 +142,14 @@ sb_status sb_sync(sb_engine *e);
 /* sb_step bracketed by HIP events on the engine's stream; *ms = device time of the n substeps. */
 sb_status sb_step_timed(sb_engine *e, uint32_t n_substeps, float *ms);
 
+/* Time marks that do not stop the host: sb_mark records HIP event number `slot` (0 .. SB_MAX_MARKS-1) at the current end of
+ * the engine's stream and returns at once; sb_mark_elapsed waits for mark b and gives the device time from mark a to mark
+ * b.  For loops that interleave sb_step with other stream work (the ghost refresh of the multi-GPU path: the bench times
+ * the substep launches and the exchanges of every rank this way without a host synchronisation per exchange). */
+#define SB_MAX_MARKS 4096
+sb_status sb_mark(sb_engine *e, uint32_t slot);
+sb_status sb_mark_elapsed(sb_engine *e, uint32_t a, uint32_t b, float *ms);
+
 /* Replaces loadBuffers() (engineWorker.ts:548-579): metadata, mapping, particles (current
  * buffer) and beams back into host ArrayBuffers of full capacity.  Only records reachable
  * through the mapping are written; other bytes of the caller's buffers are left as they are.

@@ -521,6 +521,8 @@ sb_status sb_destroy(sb_engine *e)
     if (e->stage[0]) (void)hipHostFree(e->stage[0]);
     for (int k = 0; k < 2; k++)
         if (e->stage_done[k]) (void)hipEventDestroy(e->stage_done[k]);
+    for (hipEvent_t m : e->marks)
+        if (m) (void)hipEventDestroy(m);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1067,6 +1069,28 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
     SB_HIP(e, hipEventRecord(e->ev1, e->stream));
     SB_HIP(e, hipEventSynchronize(e->ev1));
     SB_HIP(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return SB_OK;
+}
+
+sb_status sb_mark(sb_engine *e, uint32_t slot)
+{
+    if (!e) return SB_ERR_INVALID;
+    if (slot >= SB_MAX_MARKS) SB_FAIL(e, SB_ERR_INVALID, "sb_mark: slot %u >= %d", slot, SB_MAX_MARKS);
+    SB_HIP(e, hipSetDevice(e->device));
+    if (e->marks.size() <= slot) e->marks.resize((size_t)slot + 1, nullptr);
+    if (!e->marks[slot]) SB_HIP(e, hipEventCreate(&e->marks[slot]));
+    SB_HIP(e, hipEventRecord(e->marks[slot], e->stream));
+    return SB_OK;
+}
+
+sb_status sb_mark_elapsed(sb_engine *e, uint32_t a, uint32_t b, float *ms)
+{
+    if (!e || !ms) return SB_ERR_INVALID;
+    if (a >= e->marks.size() || b >= e->marks.size() || !e->marks[a] || !e->marks[b])
+        SB_FAIL(e, SB_ERR_STATE, "sb_mark_elapsed: mark %u or %u was never recorded", a, b);
+    SB_HIP(e, hipSetDevice(e->device));
+    SB_HIP(e, hipEventSynchronize(e->marks[b]));
+    SB_HIP(e, hipEventElapsedTime(ms, e->marks[a], e->marks[b]));
     return SB_OK;
 }
 

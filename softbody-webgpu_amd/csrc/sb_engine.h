@@ -69,6 +69,7 @@ struct sb_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> marks;   // sb_mark: created on first use
     std::string err;
 
     bool loaded = false;

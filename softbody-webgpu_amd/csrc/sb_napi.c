@@ -18,6 +18,7 @@
  *   writeUserInput(h, bytes32)        ArrayBuffer/TypedArray, engineMapping.ts:323-325
  *   setPhysicsConstants(h, Float32Array(8)) / getPhysicsConstants(h) -> Float32Array(8)
  *   frame(h) / step(h, n) / deletePass(h) / haloDeleteGhosts(h) / sync(h) / stepTimed(h, n) -> ms
+ *   mark(h, slot) / markElapsed(h, a, b) -> ms
  *   getCounts(h) -> {particles, beams} / getInfo(h, key) -> number
  * multi-GPU (include/softbody.h "multi-GPU halo exchange", "direct neighbour exchange", "generic x-slab partition"):
  *   haloConfigure(h, ghostP, sendP, ghostB, sendB) / haloSetLayout(h, sendPOff, sendBOff, ghostPOff, ghostBOff)   Uint32Arrays
@@ -58,6 +59,8 @@ static struct {
     sb_status (*halo_delete_ghosts)(sb_engine *);
     sb_status (*sync)(sb_engine *);
     sb_status (*step_timed)(sb_engine *, uint32_t, float *);
+    sb_status (*mark)(sb_engine *, uint32_t);
+    sb_status (*mark_elapsed)(sb_engine *, uint32_t, uint32_t, float *);
     sb_status (*get_counts)(sb_engine *, uint32_t *, uint32_t *);
     sb_status (*get_info)(sb_engine *, const char *, uint64_t *);
     sb_status (*halo_configure)(sb_engine *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
@@ -153,6 +156,8 @@ static napi_value js_load(napi_env env, napi_callback_info info)
     SYM(halo_delete_ghosts, "sb_halo_delete_ghosts");
     SYM(sync, "sb_sync");
     SYM(step_timed, "sb_step_timed");
+    SYM(mark, "sb_mark");
+    SYM(mark_elapsed, "sb_mark_elapsed");
     SYM(get_counts, "sb_get_counts");
     SYM(get_info, "sb_get_info");
     SYM(halo_configure, "sb_halo_configure");
@@ -424,6 +429,46 @@ static napi_value js_step(napi_env env, napi_callback_info info, int timed)
 }
 static napi_value js_step_plain(napi_env env, napi_callback_info info) { return js_step(env, info, 0); }
 static napi_value js_step_timed(napi_env env, napi_callback_info info) { return js_step(env, info, 1); }
+
+/* mark(handle, slot); markElapsed(handle, a, b) -> ms */
+static napi_value js_mark(napi_env env, napi_callback_info info)
+{
+    if (!need_lib(env)) return NULL;
+    size_t argc = 2;
+    napi_value argv[2];
+    CHECK_NAPI(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    sb_engine *e = argc >= 1 ? get_engine(env, argv[0]) : NULL;
+    if (!e) return NULL;
+    uint32_t slot = 0;
+    if (argc < 2 || napi_get_value_uint32(env, argv[1], &slot) != napi_ok) {
+        napi_throw_type_error(env, NULL, "mark(handle, slot) expected");
+        return NULL;
+    }
+    sb_status st = sb.mark(e, slot);
+    if (st != SB_OK) return throw_status(env, e, st, "sb_mark");
+    return NULL;
+}
+
+static napi_value js_mark_elapsed(napi_env env, napi_callback_info info)
+{
+    if (!need_lib(env)) return NULL;
+    size_t argc = 3;
+    napi_value argv[3];
+    CHECK_NAPI(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    sb_engine *e = argc >= 1 ? get_engine(env, argv[0]) : NULL;
+    if (!e) return NULL;
+    uint32_t a = 0, b = 0;
+    if (argc < 3 || napi_get_value_uint32(env, argv[1], &a) != napi_ok || napi_get_value_uint32(env, argv[2], &b) != napi_ok) {
+        napi_throw_type_error(env, NULL, "markElapsed(handle, a, b) expected");
+        return NULL;
+    }
+    float ms = 0.f;
+    sb_status st = sb.mark_elapsed(e, a, b, &ms);
+    if (st != SB_OK) return throw_status(env, e, st, "sb_mark_elapsed");
+    napi_value v;
+    CHECK_NAPI(napi_create_double(env, (double)ms, &v));
+    return v;
+}
 
 static napi_value js_get_counts(napi_env env, napi_callback_info info)
 {
@@ -836,6 +881,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"writeUserInput", js_write_user_input}, {"setPhysicsConstants", js_set_constants},
         {"getPhysicsConstants", js_get_constants}, {"frame", js_frame}, {"step", js_step_plain},
         {"deletePass", js_delete_pass}, {"sync", js_sync}, {"stepTimed", js_step_timed},
+        {"mark", js_mark}, {"markElapsed", js_mark_elapsed},
         {"getCounts", js_get_counts}, {"getInfo", js_get_info},
         {"haloConfigure", js_halo_configure}, {"haloSetLayout", js_halo_set_layout}, {"haloPack", js_halo_pack},
         {"haloUnpack", js_halo_unpack}, {"getStream", js_get_stream}, {"peerMailbox", js_peer_mailbox}, {"peerMap", js_peer_map},

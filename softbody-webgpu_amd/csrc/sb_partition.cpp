@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <new>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/softbody.h"
@@ -77,7 +78,8 @@ static sb_status partition_create_impl(uint32_t layout, uint32_t maxP, uint32_t 
         if (isz == 2) { uint16_t v; memcpy(&v, mp + 2 * id, 2); return v; }
         return rd32(mp + 4 * id);
     };
-    sb_partition *pt = new sb_partition();
+    std::unique_ptr<sb_partition> holder(new sb_partition()); // released to the caller on success only: an exception or an
+    sb_partition *pt = holder.get();                          // early return below frees it
     pt->layout = layout; pt->world = world; pt->depth = depth; pt->P = P; pt->B = B; pt->maxP = maxP; pt->maxB = maxB;
     pt->metadata.assign(md, md + SB_METADATA_BYTES);
     pt->particles.assign(pd, pd + (size_t)maxP * SB_PARTICLE_STRIDE);
@@ -88,7 +90,6 @@ static sb_status partition_create_impl(uint32_t layout, uint32_t maxP, uint32_t 
     for (uint32_t s = 0; s < P; s++) {
         const uint32_t idx = map_get(s);
         if (idx >= maxP || slot_of_data[idx] != 0xFFFFFFFFu) {
-            delete pt;
             PFAIL(SB_ERR_INVALID, "sb_partition_create: particle slot %u maps to a bad or doubly mapped data index %u", s, idx);
         }
         slot_of_data[idx] = s;
@@ -97,14 +98,13 @@ static sb_status partition_create_impl(uint32_t layout, uint32_t maxP, uint32_t 
     std::vector<uint32_t> ba(B), bb(B); // endpoints as particle SLOTS
     for (uint32_t s = 0; s < B; s++) {
         const uint32_t idx = map_get((size_t)maxP + s);
-        if (idx >= maxB) { delete pt; PFAIL(SB_ERR_INVALID, "sb_partition_create: beam slot %u maps to data index %u >= max_beams", s, idx); }
+        if (idx >= maxB) { PFAIL(SB_ERR_INVALID, "sb_partition_create: beam slot %u maps to data index %u >= max_beams", s, idx); }
         pt->b_data_of_slot[s] = idx;
         const uint8_t *rec = pt->beams.data() + (size_t)idx * bstride;
         uint32_t a, b;
         if (layout == SB_LAYOUT_V1) { const uint32_t pr = rd32(rec); a = pr & 0xffffu; b = pr >> 16; }
         else { a = rd32(rec); b = rd32(rec + 4); }
         if (a >= maxP || b >= maxP || slot_of_data[a] == 0xFFFFFFFFu || slot_of_data[b] == 0xFFFFFFFFu) {
-            delete pt;
             PFAIL(SB_ERR_INVALID, "sb_partition_create: beam slot %u references particle data index %u/%u that no slot maps to", s, a, b);
         }
         ba[s] = slot_of_data[a];
@@ -218,7 +218,7 @@ static sb_status partition_create_impl(uint32_t layout, uint32_t maxP, uint32_t 
                 if (q.rank != r) continue;
                 for (uint32_t i : q.ghost_p) {
                     const uint32_t slot = slot_of_data[S.p_global_data[i]];
-                    if (local_p_of_slot[r][slot] == 0xFFFFFFFFu) { delete pt; PFAIL(SB_ERR_INVALID, "sb_partition_create: internal error (sent particle not local)"); }
+                    if (local_p_of_slot[r][slot] == 0xFFFFFFFFu) { PFAIL(SB_ERR_INVALID, "sb_partition_create: internal error (sent particle not local)"); }
                     pr.send_p.push_back(local_p_of_slot[r][slot]);
                 }
                 // beams: match by global data index
@@ -228,8 +228,7 @@ static sb_status partition_create_impl(uint32_t layout, uint32_t maxP, uint32_t 
                 for (uint32_t g : want) {
                     auto it = std::lower_bound(R.b_global_data.begin(), R.b_global_data.end(), g);
                     if (it == R.b_global_data.end() || *it != g) {
-                        delete pt;
-                        PFAIL(SB_ERR_INVALID, "sb_partition_create: rank %u holds a ghost beam whose owner %u does not hold it (depth %u too small?)", pr.rank, r, depth);
+                                    PFAIL(SB_ERR_INVALID, "sb_partition_create: rank %u holds a ghost beam whose owner %u does not hold it (depth %u too small?)", pr.rank, r, depth);
                     }
                     pr.send_b.push_back((uint32_t)(it - R.b_global_data.begin()));
                 }
@@ -237,10 +236,9 @@ static sb_status partition_create_impl(uint32_t layout, uint32_t maxP, uint32_t 
         }
     for (uint32_t r = 0; r < world; r++)
         if (pt->ranks[r].peers.size() > SB_MAX_PEERS) {
-            delete pt;
             PFAIL(SB_ERR_UNSUPPORTED, "sb_partition_create: rank %u would trade with %zu ranks (at most %d): fewer, wider slabs", r, pt->ranks[r].peers.size(), SB_MAX_PEERS);
         }
-    *out = pt;
+    *out = holder.release();
     return SB_OK;
 }
 

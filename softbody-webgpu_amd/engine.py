@@ -87,6 +87,8 @@ def load_library():
     L.sb_halo_delete_ghosts.argtypes = [vp]
     L.sb_sync.argtypes = [vp]
     L.sb_step_timed.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_float)]
+    L.sb_mark.argtypes = [vp, u32]
+    L.sb_mark_elapsed.argtypes = [vp, u32, u32, ctypes.POINTER(ctypes.c_float)]
     L.sb_get_counts.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.sb_get_info.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
     L.sb_halo_configure.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
@@ -204,6 +206,16 @@ class Engine:
     def step_timed(self, n):
         ms = ctypes.c_float()
         self._check(load_library().sb_step_timed(self._h, n, ctypes.byref(ms)))
+        return ms.value
+
+    def mark(self, slot):
+        """Record time mark `slot` at the current end of the engine's stream (does not wait)."""
+        self._check(load_library().sb_mark(self._h, slot))
+
+    def mark_elapsed(self, a, b):
+        """Device milliseconds from mark a to mark b (waits for b)."""
+        ms = ctypes.c_float()
+        self._check(load_library().sb_mark_elapsed(self._h, a, b, ctypes.byref(ms)))
         return ms.value
 
     def counts(self):

@@ -191,6 +191,35 @@ def mix_stiffness(buf, plan, seed=1, subticks=128):
     return buf
 
 
+class StepTimer:
+    """Device time of a rank's substep launches and of its ghost refreshes, span by span, with sb_mark: events recorded on the
+    engine's own stream, nothing waits until totals() is read (bench.py: `roofline` and the exchange cost of the N > 1 line)."""
+
+    def __init__(self, engine, max_marks=4096):
+        self.engine, self.max_marks = engine, max_marks
+        self.n, self.spans, self.dropped = 0, [], 0
+
+    def run(self, kind, fn, *args):
+        if self.n + 2 > self.max_marks:          # out of events: the span still runs, untimed (and says so)
+            self.dropped += 1
+            return fn(*args)
+        a = self.n
+        self.n += 2
+        self.engine.mark(a)
+        out = fn(*args)
+        self.engine.mark(a + 1)
+        self.spans.append((kind, a))
+        return out
+
+    def totals(self):
+        """{kind: (spans, milliseconds)} -- waits for the last mark of each span."""
+        out = {}
+        for kind, a in self.spans:
+            n, ms = out.get(kind, (0, 0.0))
+            out[kind] = (n + 1, ms + self.engine.mark_elapsed(a, a + 1))
+        return out
+
+
 class Exchanger:
     """Steps one rank's engine and refreshes its ghost zone every `plan.depth` substeps.
 
@@ -201,6 +230,8 @@ class Exchanger:
     def __init__(self, engine, plan, transport):
         self.engine, self.plan, self.transport = engine, plan, transport
         self.since = 0
+        self.timer = None            # a StepTimer while somebody wants the device times of step() (bench.py)
+        self.exchanges = 0
         self.beams_after_frames = engine.counts()[1]
         gp, sp, gb, sb_ = plan.lists()
         engine.halo_configure(gp, sp, gb, sb_)
@@ -244,18 +275,36 @@ class Exchanger:
         self.transport.exchange(self.send, self.recv, self.segs, self.engine)
         self.engine.halo_unpack(self.transport.pointer(self.recv))
 
+    def refresh_now(self):
+        """An exchange ahead of schedule (always allowed: ghosts are refreshed with valid data), so that the next one falls
+        exactly plan.depth substeps from here -- bench.py aligns its timed region with it."""
+        self.exchange()
+        self.exchanges += 1
+        self.since = 0
+
     def step(self, n):
         k = self.plan.depth
+        t = self.timer
         if not self.plan.peers or k <= 0:
-            self.engine.step(n)
+            if t is not None:
+                t.run("step", self.engine.step, n)
+            else:
+                self.engine.step(n)
             return
         while n > 0:
             m = min(n, k - self.since)
-            self.engine.step(m)
+            if t is not None:
+                t.run("step", self.engine.step, m)
+            else:
+                self.engine.step(m)
             self.since += m
             n -= m
             if self.since == k:
-                self.exchange()
+                if t is not None:
+                    t.run("exchange", self.exchange)
+                else:
+                    self.exchange()
+                self.exchanges += 1
                 self.since = 0
 
 
@@ -272,6 +321,8 @@ class PeerExchanger(Exchanger):
     def __init__(self, engine, plan, timeout_ms=10000):
         self.engine, self.plan, self.transport = engine, plan, None
         self.since = 0
+        self.timer = None
+        self.exchanges = 0
         self.timeout_ms = timeout_ms
         self.beams_after_frames = engine.counts()[1]
         gp, sp, gb, sb_ = plan.lists()

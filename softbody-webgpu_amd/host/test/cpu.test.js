@@ -106,7 +106,7 @@ const same = (ab, file) => Buffer.compare(Buffer.from(ab), fs.readFileSync(path.
     test('addon loads, exports the C-ABI wrappers, and has no CPU fallback', () => {
         const a = h.native();
         for (const f of ['create', 'destroy', 'writeBuffers', 'loadBuffers', 'writeUserInput', 'setPhysicsConstants',
-            'frame', 'step', 'sync', 'stepTimed', 'getCounts', 'getInfo', 'deletePass'])
+            'frame', 'step', 'sync', 'stepTimed', 'mark', 'markElapsed', 'getCounts', 'getInfo', 'deletePass'])
             assert.strictEqual(typeof a[f], 'function', f);
         if (process.env.SOFTBODY_EXPECT_NO_GPU === '1') {
             assert.throws(() => new h.WGPUSoftbodyEngine({}), /no CPU fallback/);

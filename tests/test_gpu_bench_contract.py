@@ -39,8 +39,31 @@ def test_default_line_carries_the_contract():
     ex = d["extra"]
     assert ex["upload_ms"] > 0 and ex["readback_ms"] > 0 and ex["config3"]["value"] > 1.0e10 and ex["config3"]["finite"]
     assert ex["single_substep_kernel"]["frac_of_hbm_peak"] > 0.4
+    # the steady-state figure DESIGN.md quotes rides in the same record (never `value`), and so do one GPU's shares of configs 4 and 5
+    assert ex["steady_state"]["steps"] == 960 and ex["steady_state"]["value"] > 1.0e10
+    assert ex["config3"]["steady_state"]["steps"] == 960
+    for k, particles in (("config4_share", 500 * 4000), ("config5_share", 1000 * 8000)):
+        assert ex[k]["particles_total"] == particles and ex[k]["value"] > 1.0e10 and 0.0 < ex[k]["roofline"]["frac"] <= 1.0
 
 
-def test_two_ranks_started_bare_on_one_gpu():
-    d = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "120", "--warmup", "30")
+def test_two_ranks_with_the_drivers_arguments():
+    """`--steps 20 --warmup 5` is what the driver runs: the timed region must hold a ghost refresh (at the default depth of
+    30 it used to hold none), and the N > 1 line carries `roofline` and `cpu_baseline` like the N = 1 line."""
+    d = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", timeout=1200)
     assert d["n_gpus"] == 2 and d["value"] > 1.0e10 and "REHEARSAL" in d["data"]
+    x = d["config"]["exchange"]
+    assert x["exchanges_in_timed_region"] >= 1 and x["ghost_depth"] == 20 and x["exchange_us_avg"] > 0 and x["transport"] == "peer"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and "share" in c
+    for k, per_gpu in (("config4", 500 * 4000), ("config5", 1000 * 8000)):
+        e = d["extra"][k]
+        assert e["n_gpus"] == 2 and e["particles_total"] == 2 * per_gpu and e["exchange"]["exchanges_in_timed_region"] >= 1
+        assert 0.0 < e["roofline"]["frac"] <= 1.0 and e["value"] > 1.0e10
+
+
+def test_two_ranks_long_region_keeps_the_depth_asked_for():
+    d = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "120", "--warmup", "30", "--no-extra", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["value"] > 1.0e10 and "REHEARSAL" in d["data"]
+    assert d["config"]["exchange"]["ghost_depth"] == 30 and d["config"]["exchange"]["exchanges_in_timed_region"] == 4
