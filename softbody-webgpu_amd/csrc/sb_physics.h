@@ -263,23 +263,37 @@ SB_DEV float sb_beam_length(float2 pa, float2 pb)
 struct SbBeamMat {
     float length, inv_length, spring, damp, yield_strain, yl, ll;
 };
+// max(|a|, |b|, |c|) in one instruction (source modifiers; spelled as asm so that no canonicalising copies appear)
+SB_DEV float sb_max3_abs(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// Forces: endpoint B gets i32(+f*s) (:129-130), endpoint A gets i32(-f*s) (:127-128).  The conversion truncates toward zero,
+// so the two are exact negatives of each other -- unless it saturates (|f*s| >= 2^31: INT_MAX on one side, INT_MIN on the
+// other) .  `mirrored` (wave-uniform) says that no lane of the wave is anywhere near that: the caller then SUBTRACTS fb from
+// A's sums (ds_sub) and fa is not computed at all -- two conversions (each the price of two plain instructions) for three
+// instructions of gate per group.  NaN converts to 0 on both sides and passes the gate as what it is: harmless.
 template <int G, bool AUX>
 SB_DEV void sb_beam_group(const float2 (&pa)[G], const float2 (&pb)[G], const SbBeamMat (&m)[G], float (&target)[G],
-                          float (&last)[G], int32_t (&fa)[G][2], int32_t (&fb)[G][2], bool (&broken)[G], float (&strain_out)[G],
-                          float (&stress_out)[G])
+                          float (&last)[G], int32_t (&fa)[G][2], int32_t (&fb)[G][2], bool &mirrored, bool (&broken)[G],
+                          float (&strain_out)[G], float (&stress_out)[G])
 {
     const float particle_force_scale = 65536.0f; // :70
     const float beam_stress_scale = 1.0f / 20.0f; // :71
-    float dx[G], dy[G], len2[G], len[G], inv_len[G];
-    bool ok = true;
+    float dx[G], dy[G], len2[G], len[G], inv_len[G], fsx[G], fsy[G];
+    // the gate as an OR of lane masks: each comparison lands in a scalar register pair and the branch tests their union
+    // (a bool carried through && and then balloted went through a VGPR and back: two vector instructions per group)
+    unsigned long long outside = 0ull;
 #pragma unroll
     for (int u = 0; u < G; u++) {
         dx[u] = pb[u].x - pa[u].x; // :103
         dy[u] = pb[u].y - pa[u].y;
         len2[u] = dx[u] * dx[u] + dy[u] * dy[u];
-        ok = ok && sb_in_sqrt_gate(len2[u]);
+        outside |= __builtin_amdgcn_ballot_w64(!(len2[u] >= 0x1p-90f)) | __builtin_amdgcn_ballot_w64(!(len2[u] <= 0x1p90f));
     }
-    if (sb_wave_all(ok)) {
+    if (outside == 0ull) {
 #pragma unroll
         for (int u = 0; u < G; u++) len[u] = sb_sqrt_gated(len2[u]); // :108 (the guard of :104 cannot fire)
 #pragma unroll
@@ -312,8 +326,19 @@ SB_DEV void sb_beam_group(const float2 (&pa)[G], const float2 (&pb)[G], const Sb
         last[u] = len[u];                                                              // :124
         fb[u][0] = sb_f32_to_i32(sx);
         fb[u][1] = sb_f32_to_i32(sy);
-        fa[u][0] = sb_f32_to_i32_neg(sx);
-        fa[u][1] = sb_f32_to_i32_neg(sy);
+        fsx[u] = sx;
+        fsy[u] = sy;
+    }
+    float big = sb_max3_abs(fsx[0], fsy[0], fsx[G - 1]);
+#pragma unroll
+    for (int u = 1; u < G; u++) big = sb_max3_abs(big, fsx[u], fsy[u]); // (the max of non-negative numbers: |big| = big)
+    mirrored = __builtin_amdgcn_ballot_w64(!(big < 0x1p30f)) == 0ull;   // (NaN operands drop out of v_max3: see above)
+    if (!mirrored) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            fa[u][0] = sb_f32_to_i32_neg(fsx[u]);
+            fa[u][1] = sb_f32_to_i32_neg(fsy[u]);
+        }
     }
 }
 

@@ -92,3 +92,67 @@ def test_momentum_drift_without_external_forces(sb, scene):
     assert np.abs(v).max() > 1e-3                      # the jittered lattice is really moving
     drift = np.abs(v.sum(axis=0)) / np.abs(v).sum(axis=0)
     assert (drift < 1e-4).all(), drift
+
+
+def settle_config3(sb, particles):
+    """The pile exactly as bench.py's `extra.config3` prepares it: uploaded, settled for 48 frames on the GPU (delete
+    passes included), read back."""
+    buf, bounds = sb.scenes.config3_buffers(particles)
+    eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=2)
+    eng.write_buffers(buf)
+    for _ in range(sb.scenes.CONFIG3_SETTLE_FRAMES):
+        eng.frame()
+    settled = eng.load_buffers(buf.copy())
+    eng.destroy()
+    assert np.isfinite(settled.particles[:settled.particle_count]).all()
+    return settled, bounds
+
+
+def same_bits(got, exp):
+    P, B = exp.particle_count, exp.beam_count
+    assert (got.particle_count, got.beam_count) == (P, B)
+    assert np.array_equal(got.particles[:P].view("u4"), exp.particles[:P].view("u4"))
+    assert got.beams.tobytes() == exp.beams.tobytes()
+    assert np.array_equal(got.mapping, exp.mapping)
+
+
+def test_config3_pile_as_benched_bit_exact_vs_oracle(sb, oracle):
+    """The scene the driver's line reports as config 3 (`scenes.config3_buffers`: ~1 M particles as a pile of the
+    reference's 9 x 4 blobs, touching, settled for 48 frames): from the settled state, 10 substeps on the GPU against the
+    oracle's grid mode, bit for bit -- and the contacts are really acting (more than a fifth of the particles differ from
+    a collision-free run of the same substeps)."""
+    n = 10
+    settled, bounds = settle_config3(sb, 1_000_000)
+    assert settled.particle_count > 990_000
+    ref = oracle.OracleEngine(bounds, 10.0, 64, 2, oracle.COLLIDE_GRID, threads=16)
+    ref.write_buffers(settled)
+    ref.step(n)
+    exp = ref.load_buffers(settled.copy())
+    outs = {}
+    for mode in (2, 0):
+        eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=settled.max_particles, max_beams=settled.max_beams,
+                        collision_mode=mode)
+        eng.write_buffers(settled)
+        eng.step(n)
+        outs[mode] = eng.load_buffers(settled.copy())
+        eng.destroy()
+    same_bits(outs[2], exp)
+    P = exp.particle_count
+    assert (outs[0].particles[:P] != outs[2].particles[:P]).any(axis=1).mean() > 0.2
+
+
+def test_config3_pile_65k_against_the_all_pairs_scan(sb, oracle):
+    """The same pile at the reference's own capacity (65 536 particles), settled on the GPU, then 6 substeps of the spatial
+    hash on the GPU against the oracle running the reference's O(P^2) scan (compute.wgsl:142-170) on the same state."""
+    n = 6
+    settled, bounds = settle_config3(sb, 65_536)
+    ref = oracle.OracleEngine(bounds, 10.0, 64, 2, oracle.COLLIDE_ALLPAIRS, threads=16)
+    ref.write_buffers(settled)
+    ref.step(n)
+    exp = ref.load_buffers(settled.copy())
+    eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=settled.max_particles, max_beams=settled.max_beams, collision_mode=2)
+    eng.write_buffers(settled)
+    eng.step(n)
+    got = eng.load_buffers(settled.copy())
+    eng.destroy()
+    same_bits(got, exp)
