@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--soup-speed", type=float, default=60.0)
     ap.add_argument("--mixed-stiffness", action="store_true",
                     help="BASELINE config 5: springs drawn from {1,3,50,500}, use with --subticks 128")
+    ap.add_argument("--rest-lengths", choices=["lattice", "current"], default="lattice",
+                    help="current: every beam rests at the present distance of its (jittered) endpoints, as beams made in the "
+                         "reference's editor do -- no two rest lengths alike, so the engine runs its material mode 1")
     ap.add_argument("--exchange", choices=["peer", "stream", "sync"], default="peer",
                     help="N>1: ghost refresh by direct stores into the neighbours' IPC-mapped mailboxes (default; "
                          "falls back to 'stream' if the mappings cannot be set up or fail their check), by RCCL "
@@ -468,6 +471,8 @@ def run_workload(ctx, a, W, H, subticks, mixed, mode, steps, warmup, named=None,
             halo.mix_stiffness(buf, plan, subticks=subticks)   # keyed by global beam id: ghosts match their owners
         else:
             sb.scenes.mix_stiffness(buf, subticks=subticks)
+    if a.rest_lengths == "current":
+        sb.scenes.rest_at_current_length(buf)    # (slab scenes: positions are those of the whole lattice, so ghosts agree)
     P_local = buf.particle_count if plan is None else plan.n_owned
     B_local = buf.beam_count if plan is None else int(plan.owned_beams.size)
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=subticks, layout=2,
@@ -538,7 +543,8 @@ def run_workload(ctx, a, W, H, subticks, mixed, mode, steps, warmup, named=None,
     workload = ("BASELINE config %s: %dx%d lattice blob per GPU, %d particles / %d beams per GPU, "
                 "%s, jitter 1.0, subticks %d, collisions %s, v2 (u32) layout%s"
                 % (cfg, W, H, P_local, B_local,
-                   "springs {1,3,50,500} (config 5 mix)" if mixed else "spring 50 damp 700",
+                   ("springs {1,3,50,500} (config 5 mix)" if mixed else "spring 50 damp 700") +
+                   (", rest length = current distance (editor-style: one length per beam)" if a.rest_lengths == "current" else ""),
                    subticks, {0: "off", 2: "grid"}[mode], placed))
     rec = {"value": P_total * steps / wall, "unit": "particle-steps/s", "ms_per_step": wall * 1e3 / steps,
            "steps": steps, "warmup": warmup, "n_gpus": world, "workload": workload, "particles_total": P_total,
@@ -656,7 +662,7 @@ def main():
                           "upload_note": "sb_write_buffers / sb_load_buffers of the whole scene, host buffers <-> HBM, "
                                          "tiling and AoS<->SoA transposes included; never part of `value`"})
         if not a.no_extra:
-            plain = not (named or shaped or a.mixed_stiffness or a.lattice_on_floor)
+            plain = not (named or shaped or a.mixed_stiffness or a.lattice_on_floor or a.rest_lengths != "lattice")
             if world == 1 and rank == 0:
                 if mode == 0 and line["roofline"] and line["roofline"]["substeps_per_launch"] > 1:
                     extra["single_substep_kernel"] = measure_single_substep(sb, a, buf, bounds, rec["workload"])

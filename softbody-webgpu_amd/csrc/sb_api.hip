@@ -425,7 +425,8 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     SB_TRY(dev_alloc(e, &e->d_acc_flag[1], T));
     SB_HIP(e, hipMemset(e->d_acc_flag[0], 0x01, std::max<size_t>(T, 1) * 4));
     SB_HIP(e, hipMemset(e->d_acc_flag[1], 0x00, std::max<size_t>(T, 1) * 4));
-    e->lds_bytes = (size_t)e->nmat * 8 * sizeof(float); // the dynamic part: material rows (particles and sums are static)
+    // the dynamic part of the kernel's LDS: material rows, and with per-entry rest lengths (mode 1) one float per entry
+    e->lds_bytes = (size_t)e->nmat * 8 * sizeof(float) + (md.mode == 1 ? (size_t)SB_BK_MAXB * SB_BK_T * sizeof(float) : 0);
     return SB_OK;
 }
 

@@ -48,7 +48,7 @@ struct SbBlockedState {
 #ifndef SB_BK_WAVES_AUX
 #define SB_BK_WAVES_AUX SB_BK_WAVES
 #endif
-template <int MAT, bool AUX>
+template <int MAT, bool AUX, bool PLAIN>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
     const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
@@ -105,7 +105,11 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
             if (acc_r) pa[i] = r.acc[p0 + q];
         }
     }
-    float tg[SB_BK_MAXB], ls[SB_BK_MAXB], ln[SB_BK_MAXB], iln[SB_BK_MAXB];
+    // MAT == 1 (rest lengths that do not fit the dictionary: every scene built the way the reference's editor builds beams):
+    // the rest length of every entry is staged in LDS behind the material rows and read per evaluation; its reciprocal is
+    // recomputed there (the short exact form).  Until r03 both sat in registers, 24 of the 128, and the variant spilled 34-47.
+    float *s_len = s_mat + SB_BK_ROW * bp.nmat;
+    float tg[SB_BK_MAXB], ls[SB_BK_MAXB], ln[SB_BK_MAXB];
 #pragma unroll
     for (int i = 0; i < SB_BK_MAXB; i++) {
         const uint32_t j = tid + (uint32_t)i * SB_BK_T;
@@ -149,8 +153,10 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
             s_fy[q] = 0;
         }
     }
+    if (MAT == 1) {
 #pragma unroll
-    for (int i = 0; i < SB_BK_MAXB; i++) iln[i] = MAT == 1 ? sb_div(1.0f, ln[i]) : 1.0f; // one IEEE divide per entry and launch
+        for (int i = 0; i < SB_BK_MAXB; i++) s_len[tid + (uint32_t)i * SB_BK_T] = ln[i];
+    }
     if (tid == 0) { // the endpoints of dead and padding entries: a unit beam nobody owns
         s_pos[SB_BK_DUMMY_A] = make_float2(0.f, 0.f);
         s_pos[SB_BK_DUMMY_B] = make_float2(1.f, 0.f);
@@ -175,11 +181,12 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     // this substep's prefixes (entries / particles whose inputs are still the true state); the next substep's are
     // requested a whole substep ahead, and all of them are wave-uniform
     uint32_t nbl = __builtin_amdgcn_readfirstlane(lc[k_run - 1]), npr = __builtin_amdgcn_readfirstlane(rc[k_run - 1]);
-#ifdef SB_BK_ABLATE_COMPUTE // diagnostic build (never shipped): load and store phases only
-    for (uint32_t s = 1; s <= k_run && prm.time_step < 0.0f; s++) {
-#else
-    for (uint32_t s = 1; s <= k_run; s++) {
+    // SB_BK_ABLATE (diagnostic builds, never shipped; tools/blocked_ablation.sh): 16 = load and store phases only, 1 = no beam
+    // phase, 2 = no particle arithmetic, 4 = no force atomics, 32 = no barriers (wrong results, timing only)
+#ifndef SB_BK_ABLATE
+#define SB_BK_ABLATE 0
 #endif
+    for (uint32_t s = 1; s <= k_run && !((SB_BK_ABLATE & 16) && prm.time_step >= 0.0f); s++) {
         uint32_t nbl_next = 0u, npr_next = 0u;
         if (s < k_run) {
             nbl_next = lc[k_run - s - 1];
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         // integrated any more and its state is never stored (owned entries are always inside the prefix).
 #pragma unroll
         for (int i0 = 0; i0 < SB_BK_MAXB; i0 += SB_BK_G) {
-            if (tid + (uint32_t)i0 * SB_BK_T < nbl) {
+            if (tid + (uint32_t)i0 * SB_BK_T < nbl && !((SB_BK_ABLATE & 1) && prm.time_step >= 0.0f)) {
                 float2 qa[SB_BK_G], qb[SB_BK_G];
                 SbBeamMat mt[SB_BK_G];
                 uint32_t la[SB_BK_G], lb[SB_BK_G];
@@ -203,25 +210,35 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                     asm volatile("" : "+v"(word[i])); // keep the unpacking inside the loop: hoisted it is 3 registers per entry
                     la[u] = word[i] & lmask;
                     lb[u] = (word[i] >> SB_BK_LBITS) & lmask;
-                    const float *row = s_mat + SB_BK_ROW * (word[i] >> (2u * SB_BK_LBITS));
+                    // the material row as two 16-byte reads (ds_read_b128: 4 LDS cycles each; the 12-byte form costs 8)
+                    const float4 *row = (const float4 *)(s_mat + SB_BK_ROW * (word[i] >> (2u * SB_BK_LBITS)));
                     qa[u] = s_pos[la[u]];
                     qb[u] = s_pos[lb[u]];
-                    mt[u].spring = row[2];
-                    mt[u].damp = row[3];
-                    mt[u].yield_strain = row[4];
+                    const float4 r0 = row[0], r1 = row[1]; // length, 1/length, spring, damp | yield, yield*length, length*limit, limit
+                    mt[u].spring = r0.z;
+                    mt[u].damp = r0.w;
+                    mt[u].yield_strain = r1.x;
                     if (MAT == 2) {
-                        mt[u].length = row[0];
-                        mt[u].inv_length = row[1];
-                        mt[u].yl = row[5];
-                        mt[u].ll = row[6];
+                        mt[u].length = r0.x;
+                        mt[u].inv_length = r0.y;
+                        mt[u].yl = r1.y;
+                        mt[u].ll = r1.z;
                     } else {
-                        mt[u].length = ln[i];
-                        mt[u].inv_length = iln[i];
-                        mt[u].yl = row[4] * ln[i];
-                        mt[u].ll = ln[i] * row[7];
+                        const float len_i = s_len[tid + (uint32_t)i * SB_BK_T];
+                        mt[u].length = len_i;
+                        mt[u].yl = r1.x * len_i;
+                        mt[u].ll = len_i * r1.w;
                     }
                     t_in[u] = tg[i];
                     l_in[u] = ls[i];
+                }
+                if (MAT == 1) { // 1 / length (IEEE), as the short exact form whenever every lane's length is an ordinary number
+                    unsigned long long odd = 0ull;
+#pragma unroll
+                    for (int u = 0; u < SB_BK_G; u++)
+                        odd |= __builtin_amdgcn_ballot_w64(!(mt[u].length >= 0x1p-45f)) | __builtin_amdgcn_ballot_w64(!(mt[u].length <= 0x1p45f));
+#pragma unroll
+                    for (int u = 0; u < SB_BK_G; u++) mt[u].inv_length = odd == 0ull ? sb_rcp_gated(mt[u].length) : sb_div(1.0f, mt[u].length);
                 }
                 if (AUX && s == k_run) {
                     // strain/stress (compute.wgsl:122-123) are outputs of the last substep of a call, for owned beams only:
@@ -242,21 +259,36 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                         }
                     }
                 }
-                sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, broken, strain, stress);
+                bool mirrored;
+                sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, mirrored, broken, strain, stress);
 #pragma unroll
                 for (int u = 0; u < SB_BK_G; u++) {
                     const int i = i0 + u;
                     tg[i] = t_in[u];
                     ls[i] = l_in[u];
                     if (__builtin_expect(broken[u], 0)) brk |= 1u << i;
-                    atomicAdd(&s_fx[la[u]], fa[u][0]);
-                    atomicAdd(&s_fy[la[u]], fa[u][1]);
-                    atomicAdd(&s_fx[lb[u]], fb[u][0]);
-                    atomicAdd(&s_fy[lb[u]], fb[u][1]);
+                }
+                if ((SB_BK_ABLATE & 4) && prm.time_step >= 0.0f) {
+                } else if (__builtin_expect(mirrored, 1)) { // A's share is minus B's: ds_sub of the same integers (sb_beam_group)
+#pragma unroll
+                    for (int u = 0; u < SB_BK_G; u++) {
+                        __hip_atomic_fetch_sub(&s_fx[la[u]], fb[u][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_sub(&s_fy[la[u]], fb[u][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_fx[lb[u]], fb[u][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_fy[lb[u]], fb[u][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SB_BK_G; u++) {
+                        atomicAdd(&s_fx[la[u]], fa[u][0]);
+                        atomicAdd(&s_fy[la[u]], fa[u][1]);
+                        atomicAdd(&s_fx[lb[u]], fb[u][0]);
+                        atomicAdd(&s_fy[lb[u]], fb[u][1]);
+                    }
                 }
             }
         }
-        __syncthreads();
+        if (!(SB_BK_ABLATE & 32)) __syncthreads();
         // ---- particle phase: consume and clear the complete sums (compute.wgsl:171-201, :184-185)
 #pragma unroll
         for (int i = 0; i < SB_BK_MAXP; i++) {
@@ -269,13 +301,13 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                 const int fx = s_fx[q], fy = s_fy[q];
                 s_fx[q] = 0;
                 s_fy[q] = 0;
-                sb_particle_finish(prm, c, particle, fx, fy);
+                if (!((SB_BK_ABLATE & 2) && prm.time_step >= 0.0f)) sb_particle_finish<PLAIN>(prm, c, particle, fx, fy);
                 s_pos[q] = particle.p;
                 pv[i] = particle.v;
                 pa[i] = particle.a;
             }
         }
-        __syncthreads();
+        if (!(SB_BK_ABLATE & 32)) __syncthreads();
         nbl = __builtin_amdgcn_readfirstlane(nbl_next);
         npr = __builtin_amdgcn_readfirstlane(npr_next);
     }
@@ -359,9 +391,24 @@ uint32_t sbk_split_call(uint32_t n, uint32_t kmax, bool fewest, uint32_t *first,
     return best_L;
 }
 
+// the mode-1 variants keep one float per entry in dynamic LDS: with the static part that is more than the 64 KB a launch may
+// take without saying so (gfx950 has 160 KB per CU: two such workgroups still fit)
+static void allow_large_lds(int device)
+{
+    static bool done[64] = {};
+    if (device < 0 || device >= 64 || done[device]) return;
+    done[device] = true;
+    const int bytes = 100 * 1024;
+    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 // n substeps as the launches sbk_split_call chooses; the last launch of a call also stores strain/stress when write_aux
 void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
 {
+    if (e->mat_mode == 1) allow_large_lds(e->device);
     uint32_t k_hi = 0, n_hi = 0;
     sbk_split_call(n, e->bk.K, e->bk.fixed_depth, &k_hi, &n_hi);
     SbBlockedPlan bp{e->bk.d_tile_p0, e->bk.d_tile_h0, e->bk.d_halo_idx, e->bk.d_ring_cnt, e->bk.d_tile_b0, e->bk.d_tile_e0,
@@ -374,16 +421,20 @@ void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
         SbBlockedState bs{e->bk.d_target[e->bk.cur], e->bk.d_last[e->bk.cur], e->bk.d_target[e->bk.cur ^ 1u],
                           e->bk.d_last[e->bk.cur ^ 1u], e->beams.strain, e->beams.stress, e->d_broken};
         SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
-#define SB_LAUNCH_B(M, A)                                                                                             \
-    k_substep_blocked<M, A><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,      \
-                                                                            e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+#define SB_LAUNCH_B(M, A, PL)                                                                                         \
+    k_substep_blocked<M, A, PL><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,  \
+                                                                                e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+#define SB_LAUNCH_BA(M, PL) do { if (aux) SB_LAUNCH_B(M, true, PL); else SB_LAUNCH_B(M, false, PL); } while (0)
+        // the constants of THIS launch (they ride in its kernarg): the reference's defaults take the plain particle phase
+        const bool plain = e->consts.drag_exp == 2.0f && e->consts.mouse_active == 0u;
         if (e->ntiles) {
             if (e->mat_mode == 2) {
-                if (aux) SB_LAUNCH_B(2, true); else SB_LAUNCH_B(2, false);
+                if (plain) SB_LAUNCH_BA(2, true); else SB_LAUNCH_BA(2, false);
             } else {
-                if (aux) SB_LAUNCH_B(1, true); else SB_LAUNCH_B(1, false);
+                if (plain) SB_LAUNCH_BA(1, true); else SB_LAUNCH_BA(1, false);
             }
         }
+#undef SB_LAUNCH_BA
 #undef SB_LAUNCH_B
         e->cur ^= 1;
         e->bk.cur ^= 1u;

@@ -789,6 +789,12 @@ SB_DEV void sb_collide_slow(const SbGrid &g, bool fresh, const SbParams &prm, fl
 
 // everything after the collision loop, compute.wgsl:171-199; fx,fy are the complete fixed-point
 // beam force sums for this particle (the atomicExchange results of :184-185).
+// PLAIN (compile time; the host launches that variant when the constants of the call say so): drag_exp == 2 and no mouse
+// grab -- the reference's defaults (engineMapping.ts:271; mouse_active is 0 unless a button is down).  The general form
+// dispatches pow() over five cases and tests the mouse per particle: all uniform, all scalar branches, about a dozen of them
+// per particle in a kernel whose scalar instructions were a quarter of its vector ones (r02 counters).  Same bits: the case
+// pow() takes for y == 2 is x * x.
+template <bool PLAIN = false>
 SB_DEV void sb_particle_finish(const SbParams &prm, const SbConsts &c, SbParticle &particle,
                                int32_t fx, int32_t fy)
 {
@@ -806,14 +812,14 @@ SB_DEV void sb_particle_finish(const SbParams &prm, const SbConsts &c, SbParticl
     }
     if (vl > 0.0f) { // :174-176
         float nx = particle.v.x * inv_vl, ny = particle.v.y * inv_vl;
-        float px = sb_pow(sb_abs(particle.v.x), c.drag_exp);
-        float py = sb_pow(sb_abs(particle.v.y), c.drag_exp);
+        float px = PLAIN ? particle.v.x * particle.v.x : sb_pow(sb_abs(particle.v.x), c.drag_exp); // (|x| * |x| == x * x, bit for bit)
+        float py = PLAIN ? particle.v.y * particle.v.y : sb_pow(sb_abs(particle.v.y), c.drag_exp);
         particle.a.x -= c.drag_coeff * px * nx;
         particle.a.y -= c.drag_coeff * py * ny;
     }
     particle.a.x += c.applied_force_x * c.user_strength; // :178
     particle.a.y += c.applied_force_y * c.user_strength;
-    if (c.mouse_active > 0u) { // :179-181
+    if (!PLAIN && c.mouse_active > 0u) { // :179-181
         float mx = c.mouse_pos_x - particle.p.x, my = c.mouse_pos_y - particle.p.y;
         if (sb_length(mx, my) < prm.particle_radius * 10.0f) {
             particle.a.x += (c.mouse_vel_x - particle.v.x) * c.user_strength - c.gravity_x;

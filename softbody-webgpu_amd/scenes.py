@@ -135,6 +135,21 @@ def hash_uniform(seed, n):
     return (x >> np.uint64(11)).astype(np.float64) / float(1 << 52) - 1.0
 
 
+def rest_at_current_length(buf):
+    """Every beam's rest length := the present distance between its endpoints, the way the reference's editor makes beams
+    (a beam drawn between two particles rests at that distance).  On a jittered lattice no two beams then share a rest
+    length: the material dictionary falls back to (spring, damp, yield, limit) rows + one length per beam (mode 1).
+    The length is computed in binary32 like compute.wgsl:103,108: sqrt(dx*dx + dy*dy), each operation rounded."""
+    B = buf.beam_count
+    a, b = buf.beams["a"][:B].astype(np.int64), buf.beams["b"][:B].astype(np.int64)
+    dx = buf.particles[b, 0] - buf.particles[a, 0]
+    dy = buf.particles[b, 1] - buf.particles[a, 1]
+    ln = np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+    for f in ("length", "target_length", "last_length"):
+        buf.beams[f][:B] = ln
+    return buf
+
+
 def mix_stiffness(buf, seed=1, subticks=128):
     """BASELINE config 5: per-beam spring drawn from {1, 3, 50, 500} (the values in main.ts:218-246)
     with damping scaled so that the explicit integrator stays inside its stability envelope at
