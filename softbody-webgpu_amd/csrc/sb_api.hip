@@ -669,15 +669,18 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             // per-thread register arrays and 12-bit local indices.  One breadth-first search to the depth asked for tells the
             // region and entry sizes of EVERY smaller depth (they are prefixes), so a plan that does not fit is re-made once, at
             // the deepest depth that does -- not once per candidate (a dense scene used to pay up to six plan builds per upload)
-            const uint32_t region_cap = std::min<uint32_t>(SB_BK_MAXP * SB_BK_T, (1u << SB_BK_LBITS) - 2u);
-            const uint32_t entry_cap = SB_BK_MAXB * SB_BK_T;
+            // (by class: the kernel keeps own and halo items in slots of their own, sb_blocked.hip)
+            auto fits = [&](uint32_t d) {
+                return bl.max_own <= SB_BK_OWNP * SB_BK_T && bl.halo_at[d] <= SB_BK_HALOP * SB_BK_T && bl.max_ownb <= SB_BK_OWNB * SB_BK_T &&
+                       bl.halo_entries_at[d] <= SB_BK_HALOB * SB_BK_T && bl.region_at[d] <= (1u << SB_BK_LBITS) - 2u;
+            };
             blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
             sb_build_blocking(bl, px, py, hb, target, blockK);
             plan_target = target;
-            if (!(bl.max_region <= region_cap && bl.max_entries <= entry_cap)) {
+            if (!fits(blockK)) {
                 uint32_t fit = 0;
                 for (uint32_t d = 1; d < blockK; d++)
-                    if (bl.region_at[d] <= region_cap && bl.entries_at[d] <= entry_cap) fit = d;
+                    if (fits(d)) fit = d;
                 blockK = fit;
                 if (blockK) sb_build_blocking(bl, px, py, hb, target, blockK);
             }

@@ -40,9 +40,21 @@ struct SbBlockedState {
     uint32_t *broken;
 };
 
-#define SB_BK_CAP (SB_BK_MAXP * SB_BK_T + 2u) // LDS records: a full region, then the two dummy endpoints
-#define SB_BK_DUMMY_A (SB_BK_CAP - 2u)
-#define SB_BK_DUMMY_B (SB_BK_CAP - 1u)
+#define SB_BK_CAP (SB_BK_MAXP * SB_BK_T + 2u + 128u) // LDS records: a full region, the two dummy endpoints, 64 more dummy pairs
+#define SB_BK_PAD0 (SB_BK_MAXP * SB_BK_T + 2u)        // ... one pair per lane, for PADDING slots (a slot of a class the tile
+// does not fill): were they all the one dummy beam, a wave of padding would send 64 lanes' force sums to the same two LDS
+// words -- same-address atomics retire one lane at a time and hold the LDS pipeline meanwhile for every wave of the CU (first
+// build with slot classes, r03: +4 us per substep from 142 padding entries per tile).  Entries removed by the delete pass
+// stay the one dummy beam: they are few.
+// A thread's particle and entry slots come in two CLASSES with registers of their own: the first SB_BK_OWNP particle slots
+// hold particles the tile owns (q = tid + i T), the others its halo (q = n_own + tid + (i - OWNP) T); the first SB_BK_OWNB
+// entry slots hold beams the tile owns, the others the halo entries.  Until r03 one slot could hold either, so the gathers of
+// the second round of loads wrote registers the first round's loads were still in flight for -- and the compiler put a full
+// s_waitcnt vmcnt(0) in front of EVERY gather (vmcnt retires in order): some fifteen serialised memory round trips per tile
+// where two were meant (profiles/r03_ablation.txt: 42 of a launch's 78 us were load and store phases).
+#define SB_LANDED(x) asm volatile("" : "+v"(x)) /* a use: the compiler's wait for x goes HERE (inside a rare branch, not at its join) */
+#define SB_BK_DUMMY_A (SB_BK_MAXP * SB_BK_T)      // (what the host packs into dummy_word, sb_api.hip upload_blocked)
+#define SB_BK_DUMMY_B (SB_BK_MAXP * SB_BK_T + 1u)
 #define SB_BK_ROW 8u // LDS material row: length, 1/length, spring, damp, yield, yield*length, length*limit, limit
 
 #ifndef SB_BK_WAVES_AUX
@@ -51,8 +63,14 @@ struct SbBlockedState {
 template <int MAT, bool AUX, bool PLAIN>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
-    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
+    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, uint32_t stagger_lo, uint32_t stagger_hi, uint32_t stagger_ticks)
 {
+    // STAGGER: the workgroups [stagger_lo, stagger_hi) of the first round start late by about one load phase, so that of
+    // the two workgroups of a CU one loads while the other computes; the rounds after inherit the shift.
+    if (blockIdx.x >= stagger_lo && blockIdx.x < stagger_hi) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < stagger_ticks) __builtin_amdgcn_s_sleep(16);
+    }
     // static LDS layout: every address below is a register plus an immediate offset
     __shared__ float2 s_pos[SB_BK_CAP];
     __shared__ int s_fx[SB_BK_CAP], s_fy[SB_BK_CAP]; // fixed-point force sums (x and y apart: consecutive particles, consecutive banks)
@@ -77,77 +95,110 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
             nb_acc |= __hip_atomic_load(&acc_flag_r[bp.tile_nb[n0 + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     }
 
-    // ---- load, in two waves of requests: (1) everything whose address follows from the tile tables -- own particles, own
-    // beam states, entry words, and the INDICES of the halo -- all issued back to back; (2) the halo gathers those indices
-    // name.  (Taking own data through the same index path as the halo made every load wait for the index loads: one more
-    // full memory latency per launch, and the load phase is latency-bound.)
-    uint32_t hidx[SB_BK_MAXP];
+    // ---- load, in two waves of requests: (1) everything whose address follows from the tile tables -- the INDICES of the halo
+    // and of the halo entries' states first (the gathers wait for them, and a wait for the k-th request is a wait for the k - 1
+    // before it), then own particles, own beam states and the entry words -- all issued back to back; (2) the gathers the
+    // indices name, into registers no request of (1) writes (slot classes, above).
+    // Every request below is UNCONDITIONAL -- a lane with nothing to fetch reads element 0 of the array and discards it: a
+    // conditional load is a branch, and behind a dozen exec-mask branches the compiler's bookkeeping of what is in flight
+    // degrades to "wait for everything" at the first use of the first index.
+    const uint32_t nh_load = np_load - n_own, nh_move = np_move - n_own, nhe = ne_load - min(n_ownb, ne_load);
+    uint32_t hidx[SB_BK_HALOP], sidx[SB_BK_HALOB];
+#pragma unroll
+    for (int i = 0; i < SB_BK_HALOP; i++) {
+        const uint32_t h = tid + (uint32_t)i * SB_BK_T;
+        hidx[i] = bp.halo_idx[h < nh_load ? h0 + h : 0u];
+    }
+#pragma unroll
+    for (int i = 0; i < SB_BK_HALOB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        sidx[i] = bp.ent_state[j < nhe ? s0 + j : 0u];
+    }
     float2 pp[SB_BK_MAXP], pv[SB_BK_MAXP], pa[SB_BK_MAXP];
 #pragma unroll
-    for (int i = 0; i < SB_BK_MAXP; i++) {
+    for (int i = 0; i < SB_BK_OWNP; i++) {
         const uint32_t q = tid + (uint32_t)i * SB_BK_T;
-        hidx[i] = (q >= n_own && q < np_load) ? bp.halo_idx[h0 + q - n_own] : 0xFFFFFFFFu;
+        pp[i] = r.pos[q < n_own ? p0 + q : 0u];
+        pv[i] = r.vel[q < n_own ? p0 + q : 0u];
+        pa[i] = make_float2(0.f, 0.f);
     }
-    uint32_t word[SB_BK_MAXB], sidx[SB_BK_MAXB];
+    float tg[SB_BK_MAXB], ls[SB_BK_MAXB], ln[SB_BK_MAXB];
+#pragma unroll
+    for (int i = 0; i < SB_BK_OWNB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        tg[i] = bs.target_r[j < n_ownb ? b0 + j : 0u];
+        ls[i] = bs.last_r[j < n_ownb ? b0 + j : 0u];
+    }
+    uint32_t word[SB_BK_MAXB];
 #pragma unroll
     for (int i = 0; i < SB_BK_MAXB; i++) {
-        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
-        word[i] = j < ne_load ? bp.ent_word[e0 + j] : bp.dummy_word;
-        sidx[i] = (j >= n_ownb && j < ne_load) ? bp.ent_state[s0 + j - n_ownb] : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int i = 0; i < SB_BK_MAXP; i++) {
-        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
-        pp[i] = pv[i] = pa[i] = make_float2(0.f, 0.f);
-        if (q < n_own) {
-            pp[i] = r.pos[p0 + q];
-            pv[i] = r.vel[p0 + q];
-            if (acc_r) pa[i] = r.acc[p0 + q];
-        }
+        const uint32_t j = i < (int)SB_BK_OWNB ? tid + (uint32_t)i * SB_BK_T : n_ownb + tid + (uint32_t)(i - (int)SB_BK_OWNB) * SB_BK_T;
+        const bool have = i < (int)SB_BK_OWNB ? j < n_ownb : j < ne_load;
+        word[i] = bp.ent_word[have ? e0 + j : 0u];
+        ln[i] = MAT == 1 ? bp.ent_length[have ? e0 + j : 0u] : 1.0f;
     }
     // MAT == 1 (rest lengths that do not fit the dictionary: every scene built the way the reference's editor builds beams):
     // the rest length of every entry is staged in LDS behind the material rows and read per evaluation; its reciprocal is
     // recomputed there (the short exact form).  Until r03 both sat in registers, 24 of the 128, and the variant spilled 34-47.
     float *s_len = s_mat + SB_BK_ROW * bp.nmat;
-    float tg[SB_BK_MAXB], ls[SB_BK_MAXB], ln[SB_BK_MAXB];
-#pragma unroll
-    for (int i = 0; i < SB_BK_MAXB; i++) {
-        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
-        tg[i] = ls[i] = ln[i] = 1.0f;
-        if (j < n_ownb) {
-            tg[i] = bs.target_r[b0 + j];
-            ls[i] = bs.last_r[b0 + j];
-        }
-        if (MAT == 1 && j < ne_load) ln[i] = bp.ent_length[e0 + j];
-    }
     // (2) the gathers
 #pragma unroll
-    for (int i = 0; i < SB_BK_MAXP; i++) {
-        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
-        if (hidx[i] != 0xFFFFFFFFu) {
-            pp[i] = r.pos[hidx[i]];
-            if (q < np_move) pv[i] = r.vel[hidx[i]];
-        }
+    for (int i = 0; i < SB_BK_HALOP; i++) {
+        const uint32_t h = tid + (uint32_t)i * SB_BK_T;
+        const uint32_t at = h < nh_load ? hidx[i] : 0u;
+        pp[SB_BK_OWNP + i] = r.pos[at];
+        pv[SB_BK_OWNP + i] = r.vel[h < nh_move ? at : 0u];
+        pa[SB_BK_OWNP + i] = make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int i = 0; i < SB_BK_HALOB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        const uint32_t at = j < nhe ? sidx[i] : 0u;
+        tg[SB_BK_OWNB + i] = bs.target_r[at];
+        ls[SB_BK_OWNB + i] = bs.last_r[at];
+    }
+    // (what the lanes with nothing to fetch hold instead: a unit beam between this lane's own pair of dummy records)
+    const uint32_t pad_word = (SB_BK_PAD0 + 2u * (tid & 63u)) | ((SB_BK_PAD0 + 2u * (tid & 63u) + 1u) << SB_BK_LBITS);
 #pragma unroll
     for (int i = 0; i < SB_BK_MAXB; i++) {
-        if (sidx[i] != 0xFFFFFFFFu) {
-            tg[i] = bs.target_r[sidx[i]];
-            ls[i] = bs.last_r[sidx[i]];
-        }
-    }
-    // halo accelerations: only when a tile that owns part of the halo has any (almost never: DESIGN.md 4.1)
-    if (__syncthreads_or(nb_acc ? 1 : 0)) {
-#pragma unroll
-        for (int i = 0; i < SB_BK_MAXP; i++) {
-            const uint32_t q = tid + (uint32_t)i * SB_BK_T;
-            if (hidx[i] != 0xFFFFFFFFu && q < np_move) pa[i] = r.acc[hidx[i]];
-        }
+        const uint32_t j = i < (int)SB_BK_OWNB ? tid + (uint32_t)i * SB_BK_T : n_ownb + tid + (uint32_t)(i - (int)SB_BK_OWNB) * SB_BK_T;
+        const bool have = i < (int)SB_BK_OWNB ? j < n_ownb : j < ne_load;
+        word[i] = have ? word[i] : pad_word;
+        tg[i] = have ? tg[i] : 1.0f;
+        ls[i] = have ? ls[i] : 1.0f;
+        if (MAT == 1) ln[i] = have ? ln[i] : 1.0f;
     }
 #pragma unroll
     for (int i = 0; i < SB_BK_MAXP; i++) {
-        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
-        if (q < np_load) {
+        const uint32_t q = i < (int)SB_BK_OWNP ? tid + (uint32_t)i * SB_BK_T : n_own + tid + (uint32_t)(i - (int)SB_BK_OWNP) * SB_BK_T;
+        const bool moves = i < (int)SB_BK_OWNP ? q < n_own : q < np_move;
+        pv[i] = moves ? pv[i] : make_float2(0.f, 0.f);
+    }
+    // accelerations: almost never (DESIGN.md 4.1 "zero accelerations"), so behind everything else -- a branch in the middle of
+    // the requests above makes the compiler lose count of what is in flight and wait for all of it
+    if (acc_r) {
+#pragma unroll
+        for (int i = 0; i < SB_BK_OWNP; i++) {
+            const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+            if (q < n_own) pa[i] = r.acc[p0 + q];
+        }
+    }
+    // halo accelerations: only when a tile that owns part of the halo has any
+    if (__syncthreads_or(nb_acc ? 1 : 0)) {
+#pragma unroll
+        for (int i = 0; i < SB_BK_HALOP; i++) {
+            const uint32_t h = tid + (uint32_t)i * SB_BK_T;
+            if (h < nh_move) pa[SB_BK_OWNP + i] = r.acc[hidx[i]];
+        }
+    }
+    // LDS index of a particle slot: own q = tid + i T, halo q = n_own + tid + (i - OWNP) T
+    const uint32_t q_halo = n_own + tid;
+#define SB_SLOT_Q(i) ((i) < (int)SB_BK_OWNP ? tid + (uint32_t)(i) * SB_BK_T : q_halo + (uint32_t)((i) - (int)SB_BK_OWNP) * SB_BK_T)
+#pragma unroll
+    for (int i = 0; i < SB_BK_MAXP; i++) {
+        const uint32_t q = SB_SLOT_Q(i);
+        const bool have = i < (int)SB_BK_OWNP ? q < n_own : q < np_load;
+        if (have) {
             s_pos[q] = pp[i];
             s_fx[q] = 0;
             s_fy[q] = 0;
@@ -157,10 +208,11 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
 #pragma unroll
         for (int i = 0; i < SB_BK_MAXB; i++) s_len[tid + (uint32_t)i * SB_BK_T] = ln[i];
     }
-    if (tid == 0) { // the endpoints of dead and padding entries: a unit beam nobody owns
-        s_pos[SB_BK_DUMMY_A] = make_float2(0.f, 0.f);
-        s_pos[SB_BK_DUMMY_B] = make_float2(1.f, 0.f);
-        s_fx[SB_BK_DUMMY_A] = s_fy[SB_BK_DUMMY_A] = s_fx[SB_BK_DUMMY_B] = s_fy[SB_BK_DUMMY_B] = 0;
+    if (tid < 65u) { // the endpoints of dead entries and of every lane's padding entries: unit beams nobody owns
+        const uint32_t a = tid == 64u ? SB_BK_DUMMY_A : SB_BK_PAD0 + 2u * tid;
+        s_pos[a] = make_float2(0.f, 0.f);
+        s_pos[a + 1u] = make_float2(1.f, 0.f);
+        s_fx[a] = s_fy[a] = s_fx[a + 1u] = s_fy[a + 1u] = 0;
     }
     for (uint32_t i = tid; i < bp.nmat; i += SB_BK_T) { // host row: length, spring, damp, yield, limit, 1/length
         const float *h = bp.mat_tab + 6u * i;
@@ -197,7 +249,9 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         // integrated any more and its state is never stored (owned entries are always inside the prefix).
 #pragma unroll
         for (int i0 = 0; i0 < SB_BK_MAXB; i0 += SB_BK_G) {
-            if (tid + (uint32_t)i0 * SB_BK_T < nbl && !((SB_BK_ABLATE & 1) && prm.time_step >= 0.0f)) {
+            // (the entry number of the group's first slot: own slots count from 0, halo slots from the tile's own beams)
+            const uint32_t j0 = i0 < (int)SB_BK_OWNB ? tid + (uint32_t)i0 * SB_BK_T : n_ownb + tid + (uint32_t)(i0 - (int)SB_BK_OWNB) * SB_BK_T;
+            if ((i0 < (int)SB_BK_OWNB ? j0 < n_ownb : j0 < nbl) && !((SB_BK_ABLATE & 1) && prm.time_step >= 0.0f)) {
                 float2 qa[SB_BK_G], qb[SB_BK_G];
                 SbBeamMat mt[SB_BK_G];
                 uint32_t la[SB_BK_G], lb[SB_BK_G];
@@ -249,8 +303,8 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                     for (int u = 0; u < SB_BK_G; u++) {
                         const int i = i0 + u;
                         uint32_t j = tid + (uint32_t)i * SB_BK_T;
-                        asm volatile("" : "+v"(j)); // (or the 24 store addresses of a thread are hoisted out of the substep loop: 48 VGPRs)
-                        if (j < n_ownb && word[i] != bp.dummy_word) {
+                        asm volatile("" : "+v"(j)); // (or the store addresses of a thread are hoisted out of the substep loop: 48 VGPRs)
+                        if (i < (int)SB_BK_OWNB && j < n_ownb && word[i] != bp.dummy_word) {
                             const float len = sb_beam_length(qa[u], qb[u]);
                             const float force_mag = (tg[i] - len) * mt[u].spring + (ls[i] - len) * mt[u].damp; // :110
                             const float strain_v = (len - tg[i]) * mt[u].inv_length;                           // :112
@@ -292,8 +346,8 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         // ---- particle phase: consume and clear the complete sums (compute.wgsl:171-201, :184-185)
 #pragma unroll
         for (int i = 0; i < SB_BK_MAXP; i++) {
-            const uint32_t q = tid + (uint32_t)i * SB_BK_T;
-            if (q < npr) {
+            const uint32_t q = SB_SLOT_Q(i);
+            if (i < (int)SB_BK_OWNP ? q < n_own : q < npr) { // (own particles are inside every prefix)
                 SbParticle particle;
                 particle.p = s_pos[q];
                 particle.v = pv[i];
@@ -312,10 +366,15 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         npr = __builtin_amdgcn_readfirstlane(npr_next);
     }
 
-    // ---- store: own particles, own beams
+    // ---- store: own particles, own beams (their slots: the first of each class).  The indices are re-derived from a thread
+    // number the compiler cannot see through: computed from `tid` they are loop-invariant, get hoisted above the substep loop
+    // as a dozen 64-bit addresses, are spilled there for want of registers and reloaded here -- scratch loads in front of the
+    // stores, i.e. waits on the in-order memory counter between them.
+    uint32_t tid_s = tid;
+    asm volatile("" : "+v"(tid_s));
 #pragma unroll
-    for (int i = 0; i < SB_BK_MAXP; i++) {
-        const uint32_t q = tid + (uint32_t)i * SB_BK_T;
+    for (int i = 0; i < SB_BK_OWNP; i++) {
+        const uint32_t q = tid_s + (uint32_t)i * SB_BK_T;
         if (q < n_own) {
             w.pos[p0 + q] = s_pos[q];
             w.vel[p0 + q] = pv[i];
@@ -325,14 +384,23 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         }
     }
 #pragma unroll
-    for (int i = 0; i < SB_BK_MAXB; i++) {
-        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+    for (int i = 0; i < SB_BK_OWNB; i++) {
+        const uint32_t j = tid_s + (uint32_t)i * SB_BK_T;
         if (j < n_ownb) {
-            const bool alive = word[i] != bp.dummy_word;
-            // a beam removed by a delete pass keeps its last state, which still has to travel to the other buffer
-            bs.target_w[b0 + j] = alive ? tg[i] : bs.target_r[b0 + j];
-            bs.last_w[b0 + j] = alive ? ls[i] : bs.last_r[b0 + j];
-            if (alive && ((brk >> i) & 1u)) atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
+            if (__builtin_expect(word[i] != bp.dummy_word, 1)) {
+                bs.target_w[b0 + j] = tg[i];
+                bs.last_w[b0 + j] = ls[i];
+                if ((brk >> i) & 1u) atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
+            } else {
+                // a beam removed by a delete pass keeps its last state, which still has to travel to the other buffer: load,
+                // wait and store all INSIDE this branch (the wait at the join of the conditional form ran on every beam and
+                // drained the stores before it, one memory round trip per slot)
+                float keep_t = bs.target_r[b0 + j], keep_l = bs.last_r[b0 + j];
+                SB_LANDED(keep_t);
+                SB_LANDED(keep_l);
+                bs.target_w[b0 + j] = keep_t;
+                bs.last_w[b0 + j] = keep_l;
+            }
         }
     }
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
@@ -369,9 +437,10 @@ static inline uint32_t cdiv_b(uint32_t a, uint32_t b) { return (a + b - 1) / b; 
 // neither "as deep as possible" nor "always the sweet spot" is right: 20 substeps are cheaper as 7 + 7 + 6 than as
 // 6 + 6 + 6 + 2, 960 are cheaper as 160 x 6 than as 137 x 7 + 1.  Candidates are BALANCED splits (L launches of depth
 // ceil(n / L) or one less) for every L from the fewest possible on; they are priced with the launch times measured on
-// BASELINE config 2 (1 M particles, r02/r03 depth sweeps; the shape of the curve, not its scale, is what decides).
+// BASELINE config 2 (1 M particles, r03 depth sweep of the de-serialised kernel: about 4 us fixed + 12 us per substep, a
+// little less per substep the deeper the launch; the shape of the curve, not its scale, is what decides).
 // Returns L; *first = ceil(n / L), *n_first = how many launches have that depth (the others have first - 1).
-static const float kLaunchCostUs[SB_BK_KMAX + 1] = {0.0f, 30.0f, 38.0f, 48.0f, 58.5f, 69.0f, 79.2f, 93.8f, 109.0f};
+static const float kLaunchCostUs[SB_BK_KMAX + 1] = {0.0f, 18.0f, 29.5f, 41.0f, 53.0f, 64.5f, 76.5f, 88.7f, 101.0f}; // r03: 5, 6, 7 measured
 uint32_t sbk_split_call(uint32_t n, uint32_t kmax, bool fewest, uint32_t *first, uint32_t *n_first)
 {
     kmax = kmax < 1u ? 1u : (kmax > SB_BK_KMAX ? SB_BK_KMAX : kmax);
@@ -411,6 +480,10 @@ void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
     if (e->mat_mode == 1) allow_large_lds(e->device);
     uint32_t k_hi = 0, n_hi = 0;
     sbk_split_call(n, e->bk.K, e->bk.fixed_depth, &k_hi, &n_hi);
+    static const float stagger_us = [] { const char *v = getenv("SB_BK_STAGGER_US"); return v ? (float)atof(v) : 0.0f; }();
+    static const uint32_t stagger_lo = [] { const char *v = getenv("SB_BK_STAGGER_LO"); return v ? (uint32_t)atoi(v) : 256u; }();
+    static const uint32_t stagger_hi = [] { const char *v = getenv("SB_BK_STAGGER_HI"); return v ? (uint32_t)atoi(v) : 512u; }();
+    const uint32_t stagger_ticks = (uint32_t)(stagger_us * 100.0f); // 100 MHz wall clock
     SbBlockedPlan bp{e->bk.d_tile_p0, e->bk.d_tile_h0, e->bk.d_halo_idx, e->bk.d_ring_cnt, e->bk.d_tile_b0, e->bk.d_tile_e0,
                      e->bk.d_tile_s0, e->bk.d_ent_word, e->bk.d_ent_state, e->bk.d_lvl_cnt, e->bk.d_tile_n0, e->bk.d_tile_nb,
                      e->bk.d_ent_length, e->d_mat, e->ntiles, e->bk.K, e->bk.cap, e->nmat, e->bk.dummy_word};
@@ -423,7 +496,7 @@ void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
         SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
 #define SB_LAUNCH_B(M, A, PL)                                                                                         \
     k_substep_blocked<M, A, PL><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,  \
-                                                                                e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+                                                                                e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1], stagger_lo, stagger_hi, stagger_ticks)
 #define SB_LAUNCH_BA(M, PL) do { if (aux) SB_LAUNCH_B(M, true, PL); else SB_LAUNCH_B(M, false, PL); } while (0)
         // the constants of THIS launch (they ride in its kernarg): the reference's defaults take the plain particle phase
         const bool plain = e->consts.drag_exp == 2.0f && e->consts.mouse_active == 0u;

@@ -54,6 +54,10 @@ struct SbBlocking {
     // (particles of ring <= k) and entry prefix (smaller ring <= k-1) of any tile, and their totals over the tiles
     std::vector<uint32_t> region_at, entries_at;
     std::vector<uint64_t> sum_region_at, sum_entries_at;
+    // ... and by class, what the kernel's slot classes must hold: the largest halo (ring 1..k) and the most halo entries
+    // (entries past the tile's own beams) of any tile at depth k; the most beams any tile owns
+    std::vector<uint32_t> halo_at, halo_entries_at;
+    uint32_t max_ownb = 0;
 };
 
 namespace sbt {
@@ -332,6 +336,9 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
     }
     t.region_at.assign(K + 1, 0);
     t.entries_at.assign(K + 1, 0);
+    t.halo_at.assign(K + 1, 0);
+    t.halo_entries_at.assign(K + 1, 0);
+    t.max_ownb = 0;
     t.sum_region_at.assign(K + 1, 0);
     t.sum_entries_at.assign(K + 1, 0);
     for (uint32_t k = 0; k < T; k++)
@@ -340,6 +347,10 @@ inline void sb_build_blocking(SbBlocking &t, const std::vector<float> &px, const
             t.entries_at[d] = std::max(t.entries_at[d], out[k].lvl_cnt[d - 1]);
             t.sum_region_at[d] += out[k].ring_cnt[d];
             t.sum_entries_at[d] += out[k].lvl_cnt[d - 1];
+            const uint32_t own = t.tile_p0[k + 1] - t.tile_p0[k], ownb = t.tile_b0[k + 1] - t.tile_b0[k];
+            t.halo_at[d] = std::max(t.halo_at[d], out[k].ring_cnt[d] - own);
+            t.halo_entries_at[d] = std::max(t.halo_entries_at[d], out[k].lvl_cnt[d - 1] - std::min(out[k].lvl_cnt[d - 1], ownb));
+            t.max_ownb = std::max(t.max_ownb, ownb);
         }
     t.halo_idx.resize(t.tile_h0[T]);
     t.ring_cnt.resize((size_t)T * (K + 1));

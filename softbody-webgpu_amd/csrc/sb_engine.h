@@ -36,6 +36,11 @@ struct SbParticleArrays {
 #ifndef SB_BK_MAXP
 #define SB_BK_MAXP (2560 / SB_BK_T) // particles per thread  -> a region holds at most 2560 particles
 #endif
+// slot classes (sb_blocked.hip): own / halo particle slots and own / halo entry slots per thread
+#define SB_BK_OWNP 2u                        // a tile owns at most 1024 particles ...
+#define SB_BK_HALOP (SB_BK_MAXP - SB_BK_OWNP) // ... and reads at most 1536 more
+#define SB_BK_OWNB 6u                        // a tile owns at most 3072 beams ...
+#define SB_BK_HALOB (SB_BK_MAXB - SB_BK_OWNB) // ... and evaluates at most 3072 more
 #define SB_BK_KMAX 8u
 // When the caller does not say: the plan is made SB_BK_KPLAN substeps deep (if the regions fit), and a call of n substeps is
 // cut into launches of at most that depth by sbk_split_call (sb_blocked.hip), which prices the candidates with the measured

@@ -97,9 +97,9 @@ def test_fallback_with_automatic_tile_size_keeps_the_particle_order(sb, oracle):
 
 
 def test_block_depth_is_lowered_until_the_region_fits(sb, oracle):
-    """K = 8 on 1024-particle tiles of a 4-beam lattice needs regions beyond the kernel's capacity: the engine lowers K
-    and says so."""
+    """K = 8 on 700-particle tiles of a 4-beam lattice needs more halo than the kernel's slots hold (1536 halo particles,
+    3072 halo entries, beside 1024 own particles and 3072 own beams): the engine lowers K and says so."""
     buf = sb.scenes.lattice_buffers(96, 96, d=25.0, origin=(100.0, 100.0), anti_diagonal=True, jitter=1.0, layout=2, strain_limit=1e9)
-    got, exp, info = both(sb, oracle, buf, K=8, n=24, bounds=4000.0, tile=1024)
+    got, exp, info = both(sb, oracle, buf, K=8, n=24, bounds=4000.0, tile=700)
     assert 1 < info["substeps_per_launch"] < 8 and info["region_particles"] <= 2560
     assert_same(got, exp, "lowered K")
