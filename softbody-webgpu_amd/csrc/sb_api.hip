@@ -360,7 +360,11 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     k.halo_entries = bl.ent_state.size();
     k.halo_particles = bl.halo_idx.size();
     k.fixed_depth = e->opt.block_substeps != 0;
-    k.k_long = k.fixed_depth ? blockK : std::min<uint32_t>(blockK, SB_BK_KLONG);
+    {
+        uint32_t first = 0, n_first = 0; // what a long call's launches look like (sbk_split_call prices the candidates)
+        sbk_split_call(960u, blockK, k.fixed_depth, &first, &n_first);
+        k.k_long = first ? first : blockK;
+    }
     for (uint32_t d = 1; d <= blockK; d++) {
         k.entries_at[d] = bl.sum_entries_at[d];
         k.region_at[d] = bl.sum_region_at[d];
@@ -416,8 +420,25 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     tm.mark("  beam state to device");
     SB_TRY(dev_alloc(e, &k.d_target[1], B));
     SB_TRY(dev_alloc(e, &k.d_last[1], B));
-    SB_HIP(e, hipMemset(k.d_target[1], 0, std::max<size_t>(B, 1) * 4));
-    SB_HIP(e, hipMemset(k.d_last[1], 0, std::max<size_t>(B, 1) * 4));
+    // the other buffer: the same targets (a tile that never yields never stores its targets: both buffers must hold them)
+    if (B) SB_HIP(e, hipMemcpyAsync(k.d_target[1], k.d_target[0], (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));
+    SB_HIP(e, hipMemsetAsync(k.d_last[1], 0, std::max<size_t>(B, 1) * 4, e->stream));
+    // plastic flags: a tile starts unyielded when every beam it owns is uploaded with target_length == length, bit for bit
+    {
+        std::vector<uint32_t> pl(std::max<uint32_t>(T, 1), 0u);
+        sbt::parallel_ranges(T, 16, [&](size_t t0, size_t t1) {
+            for (size_t t = t0; t < t1; t++)
+                for (uint32_t g = bl.tile_b0[t]; g < bl.tile_b0[t + 1] && !pl[t]; g++) {
+                    const float *f = hb[bl.beam_slot[g]].f;
+                    pl[t] = memcmp(&f[0], &f[1], 4) != 0;
+                }
+        });
+        k.pristine = std::none_of(pl.begin(), pl.begin() + T, [](uint32_t x) { return x != 0; });
+        for (int b = 0; b < 2; b++) {
+            SB_TRY(dev_alloc(e, &k.d_plastic[b], T));
+            SB_TRY(stage_put_bytes(e, k.d_plastic[b], pl.data(), std::max<size_t>(T, 1) * 4));
+        }
+    }
     e->beams.target = k.d_target[0];
     e->beams.last = k.d_last[0];
     // buffer A holds whatever accelerations were uploaded; buffer B is all zeros (engineWorker.ts:593)
@@ -661,8 +682,9 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
             const uint64_t slots = (uint64_t)std::max(cus, 1) * 2u;
-            const uint64_t rounds = std::max<uint64_t>(1, (P + slots * 1100u - 1) / (slots * 1100u));
-            target = (uint32_t)std::min<uint64_t>(1100u, std::max<uint64_t>(256u, (P + slots * rounds - 1) / (slots * rounds)));
+            const uint64_t own_cap = SB_BK_OWNP * SB_BK_T; // (the kernel's own-particle slots)
+            const uint64_t rounds = std::max<uint64_t>(1, (P + slots * own_cap - 1) / (slots * own_cap));
+            target = (uint32_t)std::min<uint64_t>(own_cap, std::max<uint64_t>(256u, (P + slots * rounds - 1) / (slots * rounds)));
         }
         if (want_blocked) {
             // the plan is made as deep as asked for (default SB_BK_KPLAN) while every tile's region still fits the kernel's
@@ -676,6 +698,13 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             };
             blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
             sb_build_blocking(bl, px, py, hb, target, blockK);
+            if (!e->opt.tile_particles && (bl.max_own > SB_BK_OWNP * SB_BK_T || bl.max_ownb > SB_BK_OWNB * SB_BK_T)) {
+                // the automatic tile size owns more than the kernel's own slots hold (a scene with four or more beams per
+                // particle): smaller tiles, once
+                const double shrink = std::min((double)(SB_BK_OWNP * SB_BK_T) / bl.max_own, (double)(SB_BK_OWNB * SB_BK_T) / std::max(bl.max_ownb, 1u));
+                target = std::max<uint32_t>(128u, (uint32_t)(target * shrink * 0.97));
+                sb_build_blocking(bl, px, py, hb, target, blockK);
+            }
             plan_target = target;
             if (!fits(blockK)) {
                 uint32_t fit = 0;
@@ -1247,7 +1276,8 @@ static uint64_t substep_bytes_model(const sb_engine *e)
         const uint32_t k = e->bk.k_long;
         const uint64_t entries = e->bk.entries_at[k], halo_entries = entries - std::min<uint64_t>(entries, nc),
                        halo_particles = e->bk.region_at[k] - std::min<uint64_t>(e->bk.region_at[k], P);
-        const uint64_t per_launch = entries * (4 + (e->mat_mode == 1 ? 4 : 0)) + halo_entries * 12 + nc * 16 + P * 32 +
+        // (targets: neither read, written nor gathered while no tile has yielded; priced as of the upload)
+        const uint64_t per_launch = entries * (4 + (e->mat_mode == 1 ? 4 : 0)) + halo_entries * (e->bk.pristine ? 8 : 12) + nc * (e->bk.pristine ? 8 : 16) + P * 32 +
                                     halo_particles * 20 + (uint64_t)e->ntiles * (8 * 4 + 8 * k) + (uint64_t)e->nmat * 24;
         return per_launch / k;
     }

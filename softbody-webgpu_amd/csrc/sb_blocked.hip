@@ -38,6 +38,13 @@ struct SbBlockedState {
     const float *target_r, *last_r;
     float *target_w, *last_w, *strain, *stress;
     uint32_t *broken;
+    // "plastic" flags, per tile and per state buffer (like the acceleration flags): 0 = every beam the tile owns still has
+    // target_length == length, bit for bit (compute.wgsl:113-116 has never fired for them), in BOTH state buffers -- such a
+    // tile neither reads nor writes its targets, and tiles around it do not gather them: 33 of a launch's 147 MB on a
+    // scene that has not yielded (BASELINE config 2).  Set for good when a beam of the tile yields (that launch stores the
+    // tile's targets, every later one reads and stores them), by an upload that holds yielded beams, by a ghost refresh.
+    const uint32_t *plastic_r;
+    uint32_t *plastic_w;
 };
 
 #define SB_BK_CAP (SB_BK_MAXP * SB_BK_T + 2u + 128u) // LDS records: a full region, the two dummy endpoints, 64 more dummy pairs
@@ -63,14 +70,8 @@ struct SbBlockedState {
 template <int MAT, bool AUX, bool PLAIN>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
-    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, uint32_t stagger_lo, uint32_t stagger_hi, uint32_t stagger_ticks)
+    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
 {
-    // STAGGER: the workgroups [stagger_lo, stagger_hi) of the first round start late by about one load phase, so that of
-    // the two workgroups of a CU one loads while the other computes; the rounds after inherit the shift.
-    if (blockIdx.x >= stagger_lo && blockIdx.x < stagger_hi) {
-        const uint64_t t0 = wall_clock64();
-        while (wall_clock64() - t0 < stagger_ticks) __builtin_amdgcn_s_sleep(16);
-    }
     // static LDS layout: every address below is a register plus an immediate offset
     __shared__ float2 s_pos[SB_BK_CAP];
     __shared__ int s_fx[SB_BK_CAP], s_fy[SB_BK_CAP]; // fixed-point force sums (x and y apart: consecutive particles, consecutive banks)
@@ -88,12 +89,19 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     // acceleration flags (DESIGN.md 4.1 "zero accelerations"): own tile, and the tiles that own the halo
     const bool acc_r = __hip_atomic_load(&acc_flag_r[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     const bool acc_w_dirty = __hip_atomic_load(&acc_flag_w[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    bool nb_acc = false;
+    const bool own_plastic = __hip_atomic_load(&bs.plastic_r[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    bool nb_acc = false, nb_plastic_lane = false;
     {
+        // (every WAVE looks at all the neighbours -- a tile has a dozen -- so that the plastic verdict is wave-uniform without
+        // a barrier in front of the requests below; the acceleration verdict is only needed after one, further down)
         const uint32_t n0 = bp.tile_n0[tile], nn = bp.tile_n0[tile + 1] - n0;
-        for (uint32_t i = tid; i < nn; i += SB_BK_T)
-            nb_acc |= __hip_atomic_load(&acc_flag_r[bp.tile_nb[n0 + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        for (uint32_t i = tid & 63u; i < nn; i += 64u) {
+            const uint32_t nb = bp.tile_nb[n0 + i];
+            nb_acc |= __hip_atomic_load(&acc_flag_r[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            nb_plastic_lane |= __hip_atomic_load(&bs.plastic_r[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        }
     }
+    const bool nb_plastic = __builtin_amdgcn_ballot_w64(nb_plastic_lane) != 0ull;
 
     // ---- load, in two waves of requests: (1) everything whose address follows from the tile tables -- the INDICES of the halo
     // and of the halo entries' states first (the gathers wait for them, and a wait for the k-th request is a wait for the k - 1
@@ -126,7 +134,6 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
 #pragma unroll
     for (int i = 0; i < SB_BK_OWNB; i++) {
         const uint32_t j = tid + (uint32_t)i * SB_BK_T;
-        tg[i] = bs.target_r[j < n_ownb ? b0 + j : 0u];
         ls[i] = bs.last_r[j < n_ownb ? b0 + j : 0u];
     }
     uint32_t word[SB_BK_MAXB];
@@ -136,6 +143,13 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         const bool have = i < (int)SB_BK_OWNB ? j < n_ownb : j < ne_load;
         word[i] = bp.ent_word[have ? e0 + j : 0u];
         ln[i] = MAT == 1 ? bp.ent_length[have ? e0 + j : 0u] : 1.0f;
+    }
+    // own targets: only a tile that has yielded fetches them (the others all read element 0: one cache line); last of this
+    // round, because the address waits for the tile's flag
+#pragma unroll
+    for (int i = 0; i < SB_BK_OWNB; i++) {
+        const uint32_t j = tid + (uint32_t)i * SB_BK_T;
+        tg[i] = bs.target_r[(own_plastic && j < n_ownb) ? b0 + j : 0u];
     }
     // MAT == 1 (rest lengths that do not fit the dictionary: every scene built the way the reference's editor builds beams):
     // the rest length of every entry is staged in LDS behind the material rows and read per evaluation; its reciprocal is
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     for (int i = 0; i < SB_BK_HALOB; i++) {
         const uint32_t j = tid + (uint32_t)i * SB_BK_T;
         const uint32_t at = j < nhe ? sidx[i] : 0u;
-        tg[SB_BK_OWNB + i] = bs.target_r[at];
+        tg[SB_BK_OWNB + i] = bs.target_r[nb_plastic ? at : 0u]; // (no tile around has yielded: nothing to gather)
         ls[SB_BK_OWNB + i] = bs.last_r[at];
     }
     // (what the lanes with nothing to fetch hold instead: a unit beam between this lane's own pair of dummy records)
@@ -229,6 +243,17 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     uint32_t brk = 0u; // bit i: entry i of this thread crossed its break limit in some substep
     bool any_acc = false;
     __syncthreads();
+    // targets nobody fetched (tiles that have never yielded: plastic flags above) are the rest lengths
+    if (!own_plastic || !nb_plastic) {
+#pragma unroll
+        for (int i = 0; i < SB_BK_MAXB; i++) {
+            const bool own = i < (int)SB_BK_OWNB;
+            const uint32_t j = own ? tid + (uint32_t)i * SB_BK_T : n_ownb + tid + (uint32_t)(i - (int)SB_BK_OWNB) * SB_BK_T;
+            const bool have = own ? j < n_ownb : j < ne_load;
+            if (have && !(own ? own_plastic : nb_plastic))
+                tg[i] = MAT == 2 ? s_mat[SB_BK_ROW * (word[i] >> (2u * SB_BK_LBITS))] : s_len[tid + (uint32_t)i * SB_BK_T];
+        }
+    }
 
     // this substep's prefixes (entries / particles whose inputs are still the true state); the next substep's are
     // requested a whole substep ahead, and all of them are wave-uniform
@@ -383,12 +408,24 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
             if (nz || acc_w_dirty) w.acc[p0 + q] = pa[i];
         }
     }
+    // has a beam of a so far unyielded tile yielded in this launch?  (compute.wgsl:113-116 moved its target off its length)
+    bool yielded = false;
+    if (!own_plastic) {
+#pragma unroll
+        for (int i = 0; i < SB_BK_OWNB; i++) {
+            const uint32_t j = tid_s + (uint32_t)i * SB_BK_T;
+            const float len_i = MAT == 2 ? s_mat[SB_BK_ROW * (word[i] >> (2u * SB_BK_LBITS))] : s_len[tid + (uint32_t)i * SB_BK_T];
+            yielded |= j < n_ownb && word[i] != bp.dummy_word && __float_as_uint(tg[i]) != __float_as_uint(len_i);
+        }
+    }
+    const bool plastic_w = own_plastic || __syncthreads_or(yielded ? 1 : 0) != 0;
+    if (tid == 0) bs.plastic_w[tile] = plastic_w ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < SB_BK_OWNB; i++) {
         const uint32_t j = tid_s + (uint32_t)i * SB_BK_T;
         if (j < n_ownb) {
             if (__builtin_expect(word[i] != bp.dummy_word, 1)) {
-                bs.target_w[b0 + j] = tg[i];
+                if (plastic_w) bs.target_w[b0 + j] = tg[i];
                 bs.last_w[b0 + j] = ls[i];
                 if ((brk >> i) & 1u) atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
             } else {
@@ -480,10 +517,6 @@ void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
     if (e->mat_mode == 1) allow_large_lds(e->device);
     uint32_t k_hi = 0, n_hi = 0;
     sbk_split_call(n, e->bk.K, e->bk.fixed_depth, &k_hi, &n_hi);
-    static const float stagger_us = [] { const char *v = getenv("SB_BK_STAGGER_US"); return v ? (float)atof(v) : 0.0f; }();
-    static const uint32_t stagger_lo = [] { const char *v = getenv("SB_BK_STAGGER_LO"); return v ? (uint32_t)atoi(v) : 256u; }();
-    static const uint32_t stagger_hi = [] { const char *v = getenv("SB_BK_STAGGER_HI"); return v ? (uint32_t)atoi(v) : 512u; }();
-    const uint32_t stagger_ticks = (uint32_t)(stagger_us * 100.0f); // 100 MHz wall clock
     SbBlockedPlan bp{e->bk.d_tile_p0, e->bk.d_tile_h0, e->bk.d_halo_idx, e->bk.d_ring_cnt, e->bk.d_tile_b0, e->bk.d_tile_e0,
                      e->bk.d_tile_s0, e->bk.d_ent_word, e->bk.d_ent_state, e->bk.d_lvl_cnt, e->bk.d_tile_n0, e->bk.d_tile_nb,
                      e->bk.d_ent_length, e->d_mat, e->ntiles, e->bk.K, e->bk.cap, e->nmat, e->bk.dummy_word};
@@ -492,11 +525,12 @@ void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
         if (n_hi) n_hi--;
         const bool aux = write_aux && k == n;
         SbBlockedState bs{e->bk.d_target[e->bk.cur], e->bk.d_last[e->bk.cur], e->bk.d_target[e->bk.cur ^ 1u],
-                          e->bk.d_last[e->bk.cur ^ 1u], e->beams.strain, e->beams.stress, e->d_broken};
+                          e->bk.d_last[e->bk.cur ^ 1u], e->beams.strain, e->beams.stress, e->d_broken, e->bk.d_plastic[e->bk.cur],
+                          e->bk.d_plastic[e->bk.cur ^ 1u]};
         SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
 #define SB_LAUNCH_B(M, A, PL)                                                                                         \
     k_substep_blocked<M, A, PL><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,  \
-                                                                                e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1], stagger_lo, stagger_hi, stagger_ticks)
+                                                                                e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
 #define SB_LAUNCH_BA(M, PL) do { if (aux) SB_LAUNCH_B(M, true, PL); else SB_LAUNCH_B(M, false, PL); } while (0)
         // the constants of THIS launch (they ride in its kernarg): the reference's defaults take the plain particle phase
         const bool plain = e->consts.drag_exp == 2.0f && e->consts.mouse_active == 0u;

@@ -60,6 +60,8 @@ struct SbBlockedDev {
              *d_tile_n0 = nullptr, *d_tile_nb = nullptr, *d_slot_e0 = nullptr, *d_slot_ent = nullptr;
     float *d_ent_length = nullptr;
     float *d_target[2] = {nullptr, nullptr}, *d_last[2] = {nullptr, nullptr};
+    uint32_t *d_plastic[2] = {nullptr, nullptr}; // per state buffer, per tile: 0 = every owned beam's target is still its rest length (sb_blocked.hip)
+    bool pristine = false;    // as of the upload: no tile had a yielded beam (the traffic model leaves the targets out then)
     uint32_t k_long = 0;      // substeps per launch of a long call (what the traffic model prices)
     bool fixed_depth = false; // the caller named the depth (sb_options.block_substeps): every call runs in the fewest launches
     uint64_t entries = 0, halo_entries = 0, halo_particles = 0; // totals of the whole plan (depth K)

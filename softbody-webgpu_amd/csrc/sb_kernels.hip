@@ -842,6 +842,9 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
     }
     // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
     if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);
+    // ... and so may ghost beams' targets have been (their owners' beams may have yielded): every tile reads and writes them from now on
+    if (e->bk.K && e->ntiles)
+        for (int b = 0; b < 2; b++) (void)hipMemsetAsync(e->bk.d_plastic[b], 0x01, (size_t)e->ntiles * 4, e->stream);
 }
 
 static inline size_t sb_mailbox_stride(uint32_t recv_floats)
