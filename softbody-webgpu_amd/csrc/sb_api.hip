@@ -133,6 +133,7 @@ static void free_scene(sb_engine *e)
     e->mapped.clear();
     e->mailbox = nullptr; // was in allocs
     e->bk = SbBlockedDev{};
+    e->hy = SbBlockedDev{};
     e->n_peers = e->peer_seq = e->send_floats = e->recv_floats = 0;
     if (e->dev_err) *e->dev_err = 0;
 }
@@ -337,9 +338,50 @@ static sb_status dev_upload(sb_engine *e, T **p, const std::vector<T, A> &v)
     return SB_OK;
 }
 
+// Beam state of a blocked plan (the engine's, or the one beside a tiled layout), one entry per beam in owner order, from the
+// records of an upload: buffer 0 = uploaded, buffer 1 = the same targets (a tile that never yields never stores its targets:
+// both buffers must hold them) and zeroed lengths; the plastic flags -- a tile starts unyielded when every beam it owns is
+// uploaded with target_length == length, bit for bit.  Gathered straight into the pinned staging chunks.
+static sb_status blocked_state_to_device(sb_engine *e, SbBlockedDev &k, const SbHostBeams &hb)
+{
+    const uint32_t B = k.nbeams, T = k.ntiles;
+    float *dst[4] = {k.d_target[0], k.d_last[0], k.d_strain, k.d_stress};
+    const int field[4] = {1, 2, 7, 8};
+    const uint32_t *slot_of = k.h_beam_slot.data();
+    for (int a = 0; a < 4 && B; a++) {
+        const int fld = field[a];
+        SB_TRY(stage_put(e, dst[a], (size_t)B * 4, [&](size_t off, size_t len, uint8_t *out) {
+            float *o = (float *)out;
+            const size_t g_first = off / 4, n = len / 4;
+            sbt::parallel_ranges(n, 1 << 16, [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; i++) o[i] = hb[slot_of[g_first + i]].f[fld];
+            });
+        }));
+    }
+    if (B) SB_HIP(e, hipMemcpyAsync(k.d_target[1], k.d_target[0], (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));
+    SB_HIP(e, hipMemsetAsync(k.d_last[1], 0, std::max<size_t>(B, 1) * 4, e->stream));
+    std::vector<uint32_t> pl(std::max<uint32_t>(T, 1), 0u);
+    sbt::parallel_ranges(T, 16, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; t++)
+            for (uint32_t g = k.h_tile_b0[t]; g < k.h_tile_b0[t + 1] && !pl[t]; g++) {
+                const float *f = hb[slot_of[g]].f;
+                pl[t] = memcmp(&f[0], &f[1], 4) != 0;
+            }
+    });
+    k.pristine = std::none_of(pl.begin(), pl.begin() + T, [](uint32_t x) { return x != 0; });
+    for (int b = 0; b < 2; b++) SB_TRY(stage_put_bytes(e, k.d_plastic[b], pl.data(), std::max<size_t>(T, 1) * 4));
+    k.cur = 0;
+    return SB_OK;
+}
+
 // device side of the temporally blocked plan; on return blockK is 0 if the scene cannot use it (more material rows
 // than the 8 spare bits of an entry word address) and the caller falls back to the single-substep tiling
-static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHostBeams &hb, uint32_t &blockK, SbStageTimer &tm)
+// `hybrid`: the plan goes into e->hy, BESIDE the tiled layout of an SB_COLLIDE_GRID engine (which stays the layout every other
+// entry point sees), with beam-state, strain/stress and break-flag arrays of its own; `tiled_copy_of_slot` / `tiled_copy_slot`
+// are that layout's maps (beam slot -> one of its copies; copy -> beam slot).
+static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHostBeams &hb, uint32_t &blockK, SbStageTimer &tm,
+                                bool hybrid = false, const std::vector<uint32_t> *tiled_copy_of_slot = nullptr,
+                                const std::vector<uint32_t> *tiled_copy_slot = nullptr)
 {
     const uint32_t B = (uint32_t)hb.size(), T = bl.ntiles;
     SbMatDict md;
@@ -351,7 +393,7 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
         return SB_OK;
     }
     tm.mark("  material dictionary");
-    SbBlockedDev &k = e->bk;
+    SbBlockedDev &k = hybrid ? e->hy : e->bk;
     k.K = blockK;
     k.cap = bl.max_region;
     k.dummy_word = (SB_BK_MAXP * SB_BK_T) | ((SB_BK_MAXP * SB_BK_T + 1u) << SB_BK_LBITS); // the two dummy LDS records, material row 0
@@ -369,15 +411,24 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
         k.entries_at[d] = bl.sum_entries_at[d];
         k.region_at[d] = bl.sum_region_at[d];
     }
-    e->ntiles = T;
-    e->nhalo = (uint32_t)bl.halo_idx.size();
-    e->tile_cap_own = bl.max_own;
-    e->tile_cap_all = bl.max_region;
-    e->mat_mode = md.mode;
-    e->lbits = SB_BK_LBITS;
-    e->nmat = (uint32_t)(md.table.size() / 6);
-    e->nbeam = B;
-    e->h_copy_of_slot.assign(bl.g_of_slot.begin(), bl.g_of_slot.end());
+    k.ntiles = T;
+    k.nbeams = B;
+    k.mat_mode = md.mode;
+    k.nmat = (uint32_t)(md.table.size() / 6);
+    // the dynamic part of the kernel's LDS: material rows, and with per-entry rest lengths (mode 1) one float per entry
+    k.lds_bytes = (size_t)k.nmat * 8 * sizeof(float) + (md.mode == 1 ? (size_t)SB_BK_MAXB * SB_BK_T * sizeof(float) : 0);
+    if (!hybrid) {
+        e->ntiles = T;
+        e->nhalo = (uint32_t)bl.halo_idx.size();
+        e->tile_cap_own = bl.max_own;
+        e->tile_cap_all = bl.max_region;
+        e->mat_mode = md.mode;
+        e->lbits = SB_BK_LBITS;
+        e->nmat = k.nmat;
+        e->nbeam = B;
+        e->lds_bytes = k.lds_bytes;
+        e->h_copy_of_slot.assign(bl.g_of_slot.begin(), bl.g_of_slot.end());
+    }
     sbt::uvec<uint32_t> words(bl.ent_la.size());
     sbt::uvec<float> lengths;
     if (md.mode == 1) lengths.resize(words.size());
@@ -404,41 +455,54 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     SB_TRY(dev_upload(e, &k.d_slot_e0, bl.slot_e0));
     SB_TRY(dev_upload(e, &k.d_slot_ent, bl.slot_ent));
     SB_TRY(dev_upload(e, &k.d_ent_length, lengths));
-    SB_TRY(dev_upload(e, &e->d_mat, md.table));
-    SB_TRY(dev_upload(e, &e->beams.slot, bl.beam_slot));
-    tm.mark("  plan arrays to device");
-    // beam state, one entry per beam in owner order; buffer 0 = uploaded, buffer 1 = scratch
-    sbt::uvec<float> tmp(B);
-    float **dst[4] = {&k.d_target[0], &k.d_last[0], &e->beams.strain, &e->beams.stress};
-    const int field[4] = {1, 2, 7, 8};
-    for (int a = 0; a < 4; a++) {
-        sbt::parallel_ranges(B, 1 << 16, [&](size_t g0, size_t g1) {
-            for (size_t g = g0; g < g1; g++) tmp[g] = hb[bl.beam_slot[g]].f[field[a]];
-        });
-        SB_TRY(dev_upload(e, dst[a], tmp));
+    SB_TRY(dev_upload(e, &k.d_mat, md.table));
+    uint32_t *d_beam_slot = nullptr;
+    SB_TRY(dev_upload(e, &d_beam_slot, bl.beam_slot));
+    if (!hybrid) {
+        e->d_mat = k.d_mat;
+        e->beams.slot = d_beam_slot;
     }
-    tm.mark("  beam state to device");
+    // what an upload of the same topology needs again (rewrite_scene_state): the words as they are now, the two host maps
+    SB_TRY(dev_alloc(e, &k.d_ent_word0, words.size()));
+    if (!words.empty()) SB_HIP(e, hipMemcpyAsync(k.d_ent_word0, k.d_ent_word, words.size() * 4, hipMemcpyDeviceToDevice, e->stream));
+    k.h_beam_slot.assign(bl.beam_slot.begin(), bl.beam_slot.end());
+    k.h_tile_b0.assign(bl.tile_b0.begin(), bl.tile_b0.end());
+    tm.mark("  plan arrays to device");
+    float **dst[4] = {&k.d_target[0], &k.d_last[0], &k.d_strain, &k.d_stress};
+    for (int a = 0; a < 4; a++) SB_TRY(dev_alloc(e, dst[a], B));
     SB_TRY(dev_alloc(e, &k.d_target[1], B));
     SB_TRY(dev_alloc(e, &k.d_last[1], B));
-    // the other buffer: the same targets (a tile that never yields never stores its targets: both buffers must hold them)
-    if (B) SB_HIP(e, hipMemcpyAsync(k.d_target[1], k.d_target[0], (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));
-    SB_HIP(e, hipMemsetAsync(k.d_last[1], 0, std::max<size_t>(B, 1) * 4, e->stream));
-    // plastic flags: a tile starts unyielded when every beam it owns is uploaded with target_length == length, bit for bit
-    {
-        std::vector<uint32_t> pl(std::max<uint32_t>(T, 1), 0u);
-        sbt::parallel_ranges(T, 16, [&](size_t t0, size_t t1) {
-            for (size_t t = t0; t < t1; t++)
-                for (uint32_t g = bl.tile_b0[t]; g < bl.tile_b0[t + 1] && !pl[t]; g++) {
-                    const float *f = hb[bl.beam_slot[g]].f;
-                    pl[t] = memcmp(&f[0], &f[1], 4) != 0;
-                }
+    for (int b = 0; b < 2; b++) SB_TRY(dev_alloc(e, &k.d_plastic[b], T));
+    SB_TRY(blocked_state_to_device(e, k, hb));
+    tm.mark("  beam state to device");
+    if (hybrid) {
+        // break flags of its own (merged into the tiled layout's on the way back), the maps between the two layouts, the
+        // running state of a tracked run
+        SB_TRY(dev_alloc(e, &k.d_broken, (B + 31) / 32));
+        SB_TRY(dev_alloc(e, &k.d_broken_new, (B + 31) / 32));
+        SB_HIP(e, hipMemsetAsync(k.d_broken, 0, std::max<size_t>((B + 31) / 32, 1) * 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(k.d_broken_new, 0, std::max<size_t>((B + 31) / 32, 1) * 4, e->stream));
+        sbt::uvec<uint32_t> copy_of_g(B), g_of_copy(tiled_copy_slot->size());
+        sbt::parallel_ranges(B, 1 << 16, [&](size_t g0, size_t g1) {
+            for (size_t g = g0; g < g1; g++) copy_of_g[g] = (*tiled_copy_of_slot)[bl.beam_slot[g]];
         });
-        k.pristine = std::none_of(pl.begin(), pl.begin() + T, [](uint32_t x) { return x != 0; });
-        for (int b = 0; b < 2; b++) {
-            SB_TRY(dev_alloc(e, &k.d_plastic[b], T));
-            SB_TRY(stage_put_bytes(e, k.d_plastic[b], pl.data(), std::max<size_t>(T, 1) * 4));
-        }
+        sbt::parallel_ranges(g_of_copy.size(), 1 << 16, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; c++) g_of_copy[c] = (*tiled_copy_slot)[c] == 0xFFFFFFFFu ? 0xFFFFFFFFu : bl.g_of_slot[(*tiled_copy_slot)[c]];
+        });
+        SB_TRY(dev_upload(e, &k.d_copy_of_g, copy_of_g));
+        SB_TRY(dev_upload(e, &k.d_g_of_copy, g_of_copy));
+        SB_TRY(dev_alloc(e, &k.d_q, 1));
+        SB_TRY(dev_alloc(e, &k.d_dmax, 3 * (size_t)T));
+        SB_HIP(e, hipMemsetAsync(k.d_dmax, 0, std::max<size_t>(3 * (size_t)T, 1) * 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(k.d_q, 0, sizeof(SbHybridCtl), e->stream));
+        k.synced_delete_gen = 0;
+        k.slow_chunk = 0;
+        k.slow_left = 0;
+        return SB_OK;
     }
+    k.d_broken = nullptr; // (set by the caller once the engine's mask exists)
+    e->beams.strain = k.d_strain;
+    e->beams.stress = k.d_stress;
     e->beams.target = k.d_target[0];
     e->beams.last = k.d_last[0];
     // buffer A holds whatever accelerations were uploaded; buffer B is all zeros (engineWorker.ts:593)
@@ -446,8 +510,6 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     SB_TRY(dev_alloc(e, &e->d_acc_flag[1], T));
     SB_HIP(e, hipMemset(e->d_acc_flag[0], 0x01, std::max<size_t>(T, 1) * 4));
     SB_HIP(e, hipMemset(e->d_acc_flag[1], 0x00, std::max<size_t>(T, 1) * 4));
-    // the dynamic part of the kernel's LDS: material rows, and with per-entry rest lengths (mode 1) one float per entry
-    e->lds_bytes = (size_t)e->nmat * 8 * sizeof(float) + (md.mode == 1 ? (size_t)SB_BK_MAXB * SB_BK_T * sizeof(float) : 0);
     return SB_OK;
 }
 
@@ -520,7 +582,7 @@ sb_status sb_create(const sb_options *opts, sb_engine **out)
     }
     if ((r = hipSetDevice(e->device)) != hipSuccess || (r = hipStreamCreate(&e->stream)) != hipSuccess ||
         (r = hipEventCreate(&e->ev0)) != hipSuccess || (r = hipEventCreate(&e->ev1)) != hipSuccess ||
-        (r = hipHostMalloc((void **)&e->dev_err, 64, hipHostMallocMapped)) != hipSuccess) {
+        (r = hipHostMalloc((void **)&e->dev_err, 1024, hipHostMallocMapped)) != hipSuccess) {
         g_create_error = std::string("HIP init failed: ") + hipGetErrorString(r);
         delete e;
         return SB_ERR_HIP;
@@ -552,6 +614,169 @@ sb_status sb_destroy(sb_engine *e)
     return SB_OK;
 }
 
+// An upload of the SAME topology (same counts, same mapping, every beam between the same two particles with the same rest
+// length and material) as the scene on the device -- the editor moved or nudged something, or a caller steps from a saved
+// state again: everything the plan is made of (bisection, rings, entry lists, material rows, endpoint words, the hash's
+// arrays) is still right, and only state has to travel: particles, the beams' target / last lengths and strain / stress,
+// flags and masks back to "just uploaded".  10x cheaper than planning again (the reference re-uploads everything on every
+// edit: engineWorker.ts:497-507,580-597).  *kept = false: something differs, nothing was touched that the full path does
+// not write again.  SB_KEEP_PLAN=0 turns it off.
+static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint8_t *mp, const uint8_t *pd, const uint8_t *bd, bool *kept)
+{
+    *kept = false;
+    static const bool off = [] { const char *v = getenv("SB_KEEP_PLAN"); return v && atoi(v) == 0; }();
+    const uint32_t maxP = e->opt.max_particles, maxB = e->opt.max_beams, bstride = beam_stride(e);
+    const uint32_t P = rd_u32(md + 4), B = rd_u32(md + 24);
+    const size_t map_bytes = (size_t)(maxP + (size_t)maxB) * map_isz(e);
+    if (off || !e->loaded || P != e->P || B != e->B || e->h_beams.size() != B || e->h_pidx.size() != P || e->h_mapping.size() != map_bytes)
+        return SB_OK;
+    if (e->n_ghost_p || e->n_send_p || e->n_ghost_b || e->n_send_b || e->n_peers || e->mailbox) return SB_OK; // (ghost zones: configured per upload)
+    SbStageTimer tm;
+    std::atomic<bool> same{true};
+    sbt::parallel_ranges(map_bytes, (size_t)1 << 20, [&](size_t a, size_t b) {
+        if (memcmp(mp + a, e->h_mapping.data() + a, b - a) != 0) same.store(false, std::memory_order_relaxed);
+    });
+    if (!same.load()) return SB_OK;
+    // beam records: endpoints and static parameters must match what the plan was made for; the state fields are taken over as
+    // we go (if a later record differs, the full path replaces every record anyway)
+    const bool v1 = e->opt.layout == SB_LAYOUT_V1;
+    sbt::parallel_ranges(B, 1 << 15, [&](size_t s0, size_t s1) {
+        if (!same.load(std::memory_order_relaxed)) return;
+        for (size_t s = s0; s < s1; s++) {
+            const uint8_t *rec = bd + (size_t)map_get(e, mp, (size_t)maxP + s) * bstride; // (the mapping is the validated one)
+            uint32_t a, b;
+            float f[9];
+            if (v1) {
+                const uint32_t pair = rd_u32(rec);
+                a = pair & 0xffffu;
+                b = pair >> 16;
+                memcpy(f, rec + 4, sizeof f);
+            } else {
+                a = rd_u32(rec);
+                b = rd_u32(rec + 4);
+                memcpy(f, rec + 8, sizeof f);
+            }
+            SbHostBeam &h = e->h_beams[s];
+            if (a != h.da || b != h.db || memcmp(&f[0], &h.f[0], 4) != 0 || memcmp(&f[3], &h.f[3], 16) != 0) {
+                same.store(false, std::memory_order_relaxed);
+                return;
+            }
+            h.f[1] = f[1];
+            h.f[2] = f[2];
+            h.f[7] = f[7];
+            h.f[8] = f[8];
+        }
+    });
+    if (!same.load()) return SB_OK;
+    tm.mark("same topology: mapping + beam records");
+    std::vector<float2> hp(P), hv(P), ha(P);
+    {
+        struct Box { float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY; };
+        std::vector<Box> boxes(256);
+        std::atomic<uint32_t> nbox{0};
+        sbt::parallel_ranges(P, 1 << 16, [&](size_t i0, size_t i1) {
+            Box bx;
+            for (size_t i = i0; i < i1; i++) {
+                float q[6];
+                memcpy(q, pd + (size_t)e->h_pidx[i] * SB_PARTICLE_STRIDE, SB_PARTICLE_STRIDE);
+                hp[i] = make_float2(q[0], q[1]);
+                hv[i] = make_float2(q[2], q[3]);
+                ha[i] = make_float2(q[4], q[5]);
+                if (std::isfinite(q[0]) && std::isfinite(q[1])) {
+                    bx.minx = std::min(bx.minx, q[0]); bx.maxx = std::max(bx.maxx, q[0]);
+                    bx.miny = std::min(bx.miny, q[1]); bx.maxy = std::max(bx.maxy, q[1]);
+                }
+            }
+            boxes[nbox.fetch_add(1) % boxes.size()] = bx; // (P / 65536 ranges: fewer than 256 up to 16 M particles; beyond, a box may be lost
+        });                                              //  -- which only ever keeps a frame that a fresh upload would have moved)
+        if (e->opt.collision_mode == SB_COLLIDE_GRID && e->d_grid_ctl) {
+            Box all;
+            for (const Box &b : boxes) {
+                all.minx = std::min(all.minx, b.minx); all.maxx = std::max(all.maxx, b.maxx);
+                all.miny = std::min(all.miny, b.miny); all.maxy = std::max(all.maxy, b.maxy);
+            }
+            // the hash keeps its frame: fine while the scene is still inside it (outside, particles are clamped into edge
+            // cells -- correct, but slow: plan again)
+            if (all.minx <= all.maxx && !(all.minx >= e->grid.x0 && all.maxx <= e->grid.x0 + e->grid.width && all.miny >= e->grid.y0 &&
+                                          all.maxy <= e->grid.y0 + e->grid.height))
+                return SB_OK;
+        }
+    }
+    // ---- from here on the scene on the device is rewritten
+    e->h_metadata.assign(md, md + SB_METADATA_BYTES);
+    e->cur = 0;
+    e->substeps_done = 0;
+    if (e->dev_err) *e->dev_err = 0;
+    SB_TRY(stage_put_bytes(e, e->part[0].pos, hp.data(), P * sizeof(float2)));
+    SB_TRY(stage_put_bytes(e, e->part[0].vel, hv.data(), P * sizeof(float2)));
+    SB_TRY(stage_put_bytes(e, e->part[0].acc, ha.data(), P * sizeof(float2)));
+    SB_HIP(e, hipMemsetAsync(e->part[1].pos, 0, std::max<size_t>(P, 1) * sizeof(float2), e->stream));
+    SB_HIP(e, hipMemsetAsync(e->part[1].vel, 0, std::max<size_t>(P, 1) * sizeof(float2), e->stream));
+    SB_HIP(e, hipMemsetAsync(e->part[1].acc, 0, std::max<size_t>(P, 1) * sizeof(float2), e->stream));
+    tm.mark("particles to device");
+    const uint32_t nc = e->nbeam;
+    if (e->bk.K) {
+        SB_TRY(blocked_state_to_device(e, e->bk, e->h_beams));
+        e->beams.target = e->bk.d_target[0];
+        e->beams.last = e->bk.d_last[0];
+        if (e->delete_gen && e->bk.entries)
+            SB_HIP(e, hipMemcpyAsync(e->bk.d_ent_word, e->bk.d_ent_word0, (size_t)e->bk.entries * 4, hipMemcpyDeviceToDevice, e->stream));
+    } else {
+        float *dst[4] = {e->beams.target, e->beams.last, e->beams.strain, e->beams.stress};
+        const int field[4] = {1, 2, 7, 8};
+        const uint32_t *slot_of = e->h_slot_of_copy.data();
+        for (int a = 0; a < 4 && nc; a++) {
+            const int fld = field[a];
+            SB_TRY(stage_put(e, dst[a], (size_t)nc * 4, [&](size_t off, size_t len, uint8_t *out) {
+                float *o = (float *)out;
+                const size_t c_first = off / 4, n = len / 4;
+                sbt::parallel_ranges(n, 1 << 16, [&](size_t i0, size_t i1) {
+                    for (size_t i = i0; i < i1; i++) {
+                        const uint32_t sl = slot_of[c_first + i];
+                        o[i] = sl == 0xFFFFFFFFu ? 0.0f : e->h_beams[sl].f[fld];
+                    }
+                });
+            }));
+        }
+        if (e->delete_gen && e->live_words)
+            SB_HIP(e, hipMemcpyAsync(e->path == SB_PATH_TILED ? e->beams.pair : e->beams.ia, e->d_live0, e->live_words * 4,
+                                     hipMemcpyDeviceToDevice, e->stream));
+    }
+    if (e->hy.K) {
+        SbBlockedDev &h = e->hy; // (its beam state is borrowed from the tiled layout at the start of every run)
+        if (h.synced_delete_gen && h.entries)
+            SB_HIP(e, hipMemcpyAsync(h.d_ent_word, h.d_ent_word0, (size_t)h.entries * 4, hipMemcpyDeviceToDevice, e->stream));
+        h.synced_delete_gen = 0;
+        h.slow_chunk = h.slow_left = 0;
+    }
+    tm.mark("beam state to device");
+    if (e->d_acc_flag[0]) { // buffer A holds whatever accelerations were uploaded; buffer B is all zeros (engineWorker.ts:593)
+        SB_HIP(e, hipMemsetAsync(e->d_acc_flag[0], 0x01, std::max<size_t>(e->ntiles, 1) * 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_acc_flag[1], 0x00, std::max<size_t>(e->ntiles, 1) * 4, e->stream));
+    }
+    if (e->d_forces) SB_HIP(e, hipMemsetAsync(e->d_forces, 0, std::max<size_t>(P, 1) * sizeof(int2), e->stream));
+    SB_HIP(e, hipMemsetAsync(e->d_broken, 0, std::max<size_t>((nc + 31) / 32, 1) * 4, e->stream));
+    SB_HIP(e, hipMemsetAsync(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4, e->stream));
+    e->delete_gen = 0;
+    if (e->opt.collision_mode == SB_COLLIDE_GRID && e->d_grid_ctl) { // the hash: no build yet, same frame
+        SB_HIP(e, hipMemsetAsync(e->d_head, 0, e->grid_heads * 8, e->stream));
+        for (int k = 0; k < 2; k++) SB_HIP(e, hipMemsetAsync(e->d_blk_max[k], 0, e->grid_slots * 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_grid_done, 0, 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_grid_outside, 0, 8, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_grid_nonempty, 0xFF, 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_nl_count, 0, std::max<size_t>(P, 1) * 4, e->stream));
+        SB_HIP(e, hipMemcpyAsync(e->d_grid_ctl, e->grid_ctl0, sizeof e->grid_ctl0, hipMemcpyHostToDevice, e->stream));
+        e->grid_par = 0;
+        e->grid.ctl = &e->d_grid_ctl[0];
+    }
+    memcpy(&e->consts, md + 48, sizeof(SbConsts));
+    SB_HIP(e, hipStreamSynchronize(e->stream));
+    e->uploads_kept++;
+    tm.mark("flags, masks, hash + final sync");
+    *kept = true;
+    return SB_OK;
+}
+
 static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_t metadata_bytes, const void *mapping,
                            size_t mapping_bytes, const void *particles, size_t particles_bytes,
                            const void *beams, size_t beams_bytes)
@@ -579,6 +804,11 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipStreamSynchronize(e->stream));
     reap_join(e);
+    {
+        bool kept = false;
+        SB_TRY(rewrite_scene_state(e, md, mp, pd, bd, &kept));
+        if (kept) return SB_OK;
+    }
     free_scene(e);
 
     SbStageTimer tm;
@@ -670,6 +900,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     SbBlocking bl;
     uint32_t blockK = 0; // > 0: the temporally blocked plan is in use (sb_blocking.h)
     uint32_t plan_target = 0; // tile size the plan's bisection was made for
+    uint32_t tile_target_used = 0; // ... and the single-substep tiling's
     std::vector<uint32_t> order; // internal -> slot
     if (e->path == SB_PATH_TILED) {
         uint32_t target = e->opt.tile_particles ? e->opt.tile_particles : 1024;
@@ -730,6 +961,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
                     target = (uint32_t)(((uint64_t)P + slots * full - 1) / (slots * full));
             }
             sb_build_tiling(tl, px, py, hb, target);
+            tile_target_used = target;
             order = tl.order;
         }
     } else {
@@ -787,6 +1019,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_TRY(upload_blocked(e, bl, hb, blockK, tm));
         if (!blockK) // no dictionary: the single-substep tiling after all, on the SAME bisection (the particles are already on
             sb_build_tiling(tl, px, py, hb, plan_target); // the device in the blocked plan's order, which follows its tile size)
+        if (!blockK) tile_target_used = plan_target;
     }
     if (blockK) {
     } else if (e->path == SB_PATH_TILED) {
@@ -853,6 +1086,9 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     }
     const uint32_t nc = blockK ? e->nbeam : (uint32_t)c_slot.size();
     e->nbeam = nc;
+    e->h_slot_of_copy = c_slot; // (empty with a blocked plan, which keeps its own maps: SbBlockedDev::h_beam_slot)
+    e->d_live0 = nullptr;
+    e->live_words = 0;
     if (!blockK) {
         float *SbBeamArrays::*fields[9] = {&SbBeamArrays::length, &SbBeamArrays::target, &SbBeamArrays::last,
                                            &SbBeamArrays::spring, &SbBeamArrays::damp,   &SbBeamArrays::yield,
@@ -885,6 +1121,11 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             if (nc) SB_TRY(stage_put_bytes(e, e->beams.ia, c_ia.data(), (size_t)nc * 4));
             if (nc) SB_TRY(stage_put_bytes(e, e->beams.ib, c_ib.data(), (size_t)nc * 4));
         }
+        // the one array delete passes write into, as uploaded (rewrite_scene_state puts it back)
+        uint32_t *live = e->path == SB_PATH_TILED ? e->beams.pair : e->beams.ia;
+        SB_TRY(dev_alloc(e, &e->d_live0, nc));
+        if (nc) SB_HIP(e, hipMemcpyAsync(e->d_live0, live, (size_t)nc * 4, hipMemcpyDeviceToDevice, e->stream));
+        e->live_words = nc;
     }
     tm.mark("beams to device");
     // ---- spatial hash: covers the uploaded bounding box plus a margin; particles that later
@@ -941,6 +1182,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_HIP(e, hipMemset(e->d_grid_done, 0, 4));
         SB_TRY(dev_alloc(e, &e->d_grid_outside, 2));
         SB_HIP(e, hipMemset(e->d_grid_outside, 0, 8));
+        SB_TRY(dev_alloc(e, &e->d_grid_nonempty, 1));
+        SB_HIP(e, hipMemset(e->d_grid_nonempty, 0xFF, 4)); // (no lists yet: not "all empty")
         SbGridCtl ctl[2] = {};
         for (int k = 0; k < 2; k++) {
             ctl[k].force = 1;
@@ -958,6 +1201,9 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             ctl[k].since = 1000; // "the hash before the first one lasted long": start lean
         }
         SB_HIP(e, hipMemcpy(e->d_grid_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
+        memcpy(e->grid_ctl0, ctl, sizeof ctl);
+        e->grid_heads = n1;
+        e->grid_slots = 3 * nblk;
         e->grid_par = 0;
         e->grid.head = e->d_head;
         e->grid.rec = e->d_rec;
@@ -978,6 +1224,38 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     }
     SB_TRY(dev_alloc(e, &e->d_broken, (nc + 31) / 32));
     SB_HIP(e, hipMemset(e->d_broken, 0, std::max<size_t>((nc + 31) / 32, 1) * 4));
+    if (e->bk.K) e->bk.d_broken = e->d_broken;
+    // ---- SB_COLLIDE_GRID: a blocked plan BESIDE the tiled layout, on the same bisection, for the stretches of a run in which
+    // nothing is within reach of anything (every neighbour list empty: the collision loop of compute.wgsl:142-170, which the
+    // reference always runs, is then a no-op and K substeps can go out of LDS and registers as with collisions off).
+    // hybrid_substeps below decides substep run by substep run; every other entry point only ever sees the tiled layout.
+    e->hy = SbBlockedDev{};
+    {
+        static const bool hybrid_off = [] { const char *v = getenv("SB_HYBRID"); return v && atoi(v) == 0; }();
+        if (!hybrid_off && e->path == SB_PATH_TILED && e->opt.collision_mode == SB_COLLIDE_GRID && e->opt.block_substeps != 1 && P && B &&
+            tl.ntiles) {
+            uint32_t hk = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
+            SbBlocking hbl;
+            sb_build_blocking(hbl, px, py, hb, tile_target_used, hk);
+            auto fits = [&](uint32_t d) {
+                return hbl.max_own <= SB_BK_OWNP * SB_BK_T && hbl.halo_at[d] <= SB_BK_HALOP * SB_BK_T && hbl.max_ownb <= SB_BK_OWNB * SB_BK_T &&
+                       hbl.halo_entries_at[d] <= SB_BK_HALOB * SB_BK_T && hbl.region_at[d] <= (1u << SB_BK_LBITS) - 2u;
+            };
+            if (!fits(hk)) {
+                uint32_t fit = 0;
+                for (uint32_t d = 2; d < hk; d++)
+                    if (fits(d)) fit = d;
+                hk = fit;
+                if (hk) sb_build_blocking(hbl, px, py, hb, tile_target_used, hk);
+            }
+            // the two plans must agree on the particle order and on the tiles (same bisection of the same positions)
+            if (hk && hbl.order == tl.order && hbl.tile_p0 == tl.tile_p0) {
+                SB_TRY(upload_blocked(e, hbl, hb, hk, tm, true, &e->h_copy_of_slot, &c_slot));
+                if (!hk) e->hy = SbBlockedDev{};
+            }
+            tm.mark("blocked plan beside the tiling");
+        }
+    }
     SB_TRY(dev_alloc(e, &e->d_dead_gen, B));
     SB_HIP(e, hipMemset(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4));
     e->delete_gen = 0;
@@ -1031,11 +1309,122 @@ sb_status sb_get_physics_constants(sb_engine *e, float c8[8])
 
 // n substeps.  strain/stress are pure outputs (render inputs in the reference, render.wgsl:82): only the last
 // substep before control returns to the caller can ever be observed, so only it stores them.
-static void launch_substeps(sb_engine *e, uint32_t n)
+// SB_COLLIDE_GRID with a blocked plan beside the tiling (e->hy).  The reference always runs its collision loop
+// (compute.wgsl:142-170); while every neighbour list of the spatial hash is empty and the hash's displacement bound stays
+// within its skin that loop is a no-op, and K substeps can go out of LDS and registers exactly as with collisions off.  So:
+//   look   (stream sync + a few words back): lists all empty? no rebuild pending? at least half the skin left?
+//   no  -> substep by substep for a stretch that doubles while the answer stays no (a pile never pays more than a few looks),
+//          then look again;
+//   yes -> beam state into the blocked layout, a run of tracked launches (k_substep_blocked<TRACK> + k_hybrid_validate each:
+//          the launch measures what its particles move, the validation adds it to the bound; one over the skin raises a
+//          flag on the device and everything queued behind returns at once), state back into the tiled layout, the hash's
+//          bookkeeping (bound, drift, age) brought up to date; a launch that went over is simply not counted -- the buffers it
+//          read are intact (everything is double-buffered) -- and its substeps are redone one by one, where the hash gets rebuilt.
+// Every other entry point sees the tiled layout only.  Bit-exact by construction: a launch counts only if no contact could
+// have happened during it.
+static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
+{
+    SbBlockedDev &h = e->hy;
+    static const uint32_t fail_every = [] { const char *v = getenv("SB_HYBRID_FAIL_EVERY"); return v ? (uint32_t)atoi(v) : 0u; }();
+    while (n) {
+        if (h.slow_left || n < 2u) {
+            const uint32_t m = h.slow_left ? std::min(n, h.slow_left) : n;
+            for (uint32_t i = 0; i < m; i++) sbk_launch_substep(e, i + 1 == n);
+            h.slow_left -= std::min(h.slow_left, m);
+            n -= m;
+            continue;
+        }
+        // ---- look
+        struct Look { SbGridCtl ctl; uint32_t nonempty; } *look = (Look *)(e->dev_err + 16); // (pinned; words 0..15 are the error and stamp words)
+        SB_HIP(e, hipMemcpyAsync(&look->ctl, e->d_grid_ctl + e->grid_par, sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
+        sbk_launch_lists_nonempty(e); // (asked only here: a store from the list makers themselves cost the pile 5 us per substep)
+        SB_HIP(e, hipMemcpyAsync(&look->nonempty, e->d_grid_nonempty, 4, hipMemcpyDeviceToHost, e->stream));
+        SB_HIP(e, hipStreamSynchronize(e->stream));
+        const SbGridCtl ctl = look->ctl;
+        auto force_rebuild = [&]() -> sb_status { // the next maintenance launch rebuilds the hash, the substep after it makes the lists
+            for (int par = 0; par < 2; par++) SB_HIP(e, hipMemsetAsync(&e->d_grid_ctl[par].force, 0x01, 4, e->stream));
+            h.slow_left = std::min<uint32_t>(n, 2u);
+            return SB_OK;
+        };
+        if (ctl.force != 0u || ctl.builds == 0u) { // no hash yet, or one on order: two substeps make it and its lists
+            h.slow_left = std::min<uint32_t>(n, 2u);
+            continue;
+        }
+        if (look->nonempty != 0u || e->n_ghost_p != 0 || e->n_send_p != 0) { // somebody within reach (or ghost zones: not handled here)
+            h.slow_chunk = std::min<uint32_t>(std::max<uint32_t>(16u, 2u * h.slow_chunk), 1024u);
+            h.slow_left = std::min(n, h.slow_chunk);
+            continue;
+        }
+        if (!(ctl.accum <= 0.7f * ctl.skin)) { // quiet, but little of the skin left: a fresh hash is cheaper than a run that fails
+            SB_TRY(force_rebuild());
+            continue;
+        }
+        h.slow_chunk = 0;
+        // ---- a run of tracked launches
+        const uint32_t chunk = std::min<uint32_t>(n, 48u * h.K);
+        uint32_t ks[64], count = 0, k_hi = 0, n_hi = 0;
+        const uint32_t L = sbk_split_call(chunk, h.K, false, &k_hi, &n_hi);
+        for (uint32_t i = 0; i < L && count < 64u; i++) ks[count++] = i < n_hi ? k_hi : k_hi - 1u;
+        uint32_t planned = 0;
+        for (uint32_t i = 0; i < count; i++) planned += ks[i];
+        const bool aux_last = planned == n;
+        SbHybridCtl q{};
+        q.D = ctl.accum;
+        q.Cx = ctl.Cx;
+        q.Cy = ctl.Cy;
+        q.cx = ctl.cx;
+        q.cy = ctl.cy;
+        q.skin = ctl.skin;
+        q.fail_at = 0xFFFFFFFFu;
+        if (fail_every && (h.launches_ok + h.launches_failed + count) / fail_every != (h.launches_ok + h.launches_failed) / fail_every)
+            q.fail_at = fail_every - 1u - (uint32_t)((h.launches_ok + h.launches_failed) % fail_every); // (tests: a roll-back every so many launches)
+        SbHybridCtl *pin = (SbHybridCtl *)(e->dev_err + 48);
+        *pin = q;
+        SB_HIP(e, hipMemcpyAsync(h.d_q, pin, sizeof q, hipMemcpyHostToDevice, e->stream));
+        sbk_hybrid_to_blocked(e);
+        const uint32_t cur0 = e->cur, bcur0 = h.cur;
+        const uint64_t done0 = e->substeps_done;
+        sbk_hybrid_launch(e, ks, count, aux_last);
+        SB_HIP(e, hipMemcpyAsync(pin, h.d_q, sizeof q, hipMemcpyDeviceToHost, e->stream));
+        SB_HIP(e, hipStreamSynchronize(e->stream));
+        q = *pin;
+        const uint32_t done = std::min(q.done, count);
+        // the host's idea of the buffers follows what the device really did
+        e->cur = cur0 ^ (done & 1u);
+        h.cur = bcur0 ^ (done & 1u);
+        e->substeps_done = done0 + q.substeps;
+        sbk_hybrid_to_tiled(e, done == count && aux_last);
+        h.launches_ok += done;
+        h.substeps_blocked += q.substeps;
+        // the hash's bookkeeping, as if its maintenance launch had run on every one of those substeps; the displacement
+        // slots that launch reads next are from before the run (any drift estimate keeps the bound valid: zero)
+        SbGridCtl upd = ctl;
+        upd.accum = q.D;
+        upd.Cx = q.Cx;
+        upd.Cy = q.Cy;
+        upd.cx = q.cx;
+        upd.cy = q.cy;
+        upd.since = ctl.since + q.substeps;
+        look->ctl = upd;
+        SB_HIP(e, hipMemcpyAsync(e->d_grid_ctl + e->grid_par, &look->ctl, sizeof(SbGridCtl), hipMemcpyHostToDevice, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_blk_max[e->grid_par], 0, 3 * (size_t)(std::max<size_t>(e->ntiles, ((size_t)e->P + 255) / 256) + 1) * 4, e->stream));
+        SB_HIP(e, hipStreamSynchronize(e->stream)); // (`look` is reused by the next look)
+        n -= q.substeps;
+        if (done < count) { // over the budget (or told to fail, by a test): a fresh hash, then look again
+            h.launches_failed += 1;
+            SB_TRY(force_rebuild());
+        }
+    }
+    return SB_OK;
+}
+
+static sb_status launch_substeps(sb_engine *e, uint32_t n)
 {
     if (e->bk.K) sbk_launch_blocked(e, n, true);
+    else if (e->hy.K) return hybrid_substeps(e, n);
     else
         for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
+    return SB_OK;
 }
 
 sb_status sb_step(sb_engine *e, uint32_t n)
@@ -1043,7 +1432,7 @@ sb_status sb_step(sb_engine *e, uint32_t n)
     if (!e) return SB_ERR_INVALID;
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
-    launch_substeps(e, n);
+    SB_TRY(launch_substeps(e, n));
     SB_HIP(e, hipGetLastError());
     return SB_OK;
 }
@@ -1097,7 +1486,7 @@ sb_status sb_step_timed(sb_engine *e, uint32_t n, float *ms)
     if (!e->loaded) SB_FAIL(e, SB_ERR_STATE, "sb_step_timed before sb_write_buffers");
     SB_HIP(e, hipSetDevice(e->device));
     SB_HIP(e, hipEventRecord(e->ev0, e->stream));
-    launch_substeps(e, n);
+    SB_TRY(launch_substeps(e, n));
     SB_HIP(e, hipGetLastError());
     SB_HIP(e, hipEventRecord(e->ev1, e->stream));
     SB_HIP(e, hipEventSynchronize(e->ev1));
@@ -1307,6 +1696,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "device_bytes") *value = e->device_bytes;
     else if (k == "substeps_done") *value = e->substeps_done;
     else if (k == "lds_bytes") *value = e->lds_bytes;
+    else if (k == "uploads_kept") *value = e->uploads_kept;
     else if (k == "kernels_per_substep")
         *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 1 : 0);
     else if (k == "grid_cells") *value = e->ncell;
@@ -1354,6 +1744,9 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
         SB_HIP(e, hipStreamSynchronize(e->stream));
         *value = (i >= 0 && i < 7 && e->dev_err) ? e->dev_err[4 + i] : 0;
     }
+    else if (k == "hybrid") *value = e->hy.K;                         // depth of the blocked plan beside the tiling (0: none)
+    else if (k == "hybrid_substeps") *value = e->hy.substeps_blocked; // substeps that ran blocked under SB_COLLIDE_GRID
+    else if (k == "hybrid_failed") *value = e->hy.launches_failed;    // tracked launches that went over the skin and were redone
     else if (k == "material_mode") *value = e->mat_mode;
     else if (k == "materials") *value = e->nmat;
     else if (k == "local_index_bits") *value = e->lbits;

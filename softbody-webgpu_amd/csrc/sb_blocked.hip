@@ -67,11 +67,32 @@ struct SbBlockedState {
 #ifndef SB_BK_WAVES_AUX
 #define SB_BK_WAVES_AUX SB_BK_WAVES
 #endif
-template <int MAT, bool AUX, bool PLAIN>
+// TRACK (SB_COLLIDE_GRID engines, sb_api.hip hybrid_step): the launch runs while every neighbour list of the spatial hash is
+// empty, i.e. while the collision loop of compute.wgsl:142-170 is a no-op -- which holds as long as no particle has moved
+// more than the hash's skin relative to the common drift since the lists were made.  So the kernel measures what its own
+// particles move, substep by substep, against the drift (cx, cy) and leaves the largest sum any of its threads saw in
+// dmax[tile] (every particle is integrated by one thread throughout, so a thread's sum of per-substep maxima bounds the path
+// of each of its particles); k_hybrid_validate adds the launch's maximum to the hash's running bound and raises *bad when
+// that exceeds the skin -- the launches queued behind then return at once and the host redoes the block substep by substep.
+struct SbTrack {
+    const SbHybridCtl *q; // bad (sticky: return at once), cx / cy (the drift this launch measures against: the mean displacement
+                          // in the last substep of the launch before, by one sample particle per tile)
+    uint32_t *dmax;       // [ntiles] displacement sums, then [2 ntiles] the samples (dx, dy of each tile's first particle, last substep)
+    uint32_t ntiles;
+    uint32_t *any_broken; // raised when the launch flags a beam: its flags sit in a mask of their own until the launch is validated
+};
+template <int MAT, bool AUX, bool PLAIN, bool TRACK>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
-    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w)
+    const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, SbTrack tr)
 {
+    if (TRACK && __hip_atomic_load(&tr.q->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return; // (uniform: every lane reads the one word)
+    float moved_sum = 0.0f; // TRACK: sum over the substeps of this thread's largest drift-relative displacement
+    float track_cx = 0.0f, track_cy = 0.0f;
+    if (TRACK) {
+        track_cx = __uint_as_float(__hip_atomic_load((const uint32_t *)&tr.q->cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        track_cy = __uint_as_float(__hip_atomic_load((const uint32_t *)&tr.q->cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     // static LDS layout: every address below is a register plus an immediate offset
     __shared__ float2 s_pos[SB_BK_CAP];
     __shared__ int s_fx[SB_BK_CAP], s_fy[SB_BK_CAP]; // fixed-point force sums (x and y apart: consecutive particles, consecutive banks)
@@ -369,6 +390,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         }
         if (!(SB_BK_ABLATE & 32)) __syncthreads();
         // ---- particle phase: consume and clear the complete sums (compute.wgsl:171-201, :184-185)
+        float moved_now = 0.0f;
 #pragma unroll
         for (int i = 0; i < SB_BK_MAXP; i++) {
             const uint32_t q = SB_SLOT_Q(i);
@@ -380,12 +402,23 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                 const int fx = s_fx[q], fy = s_fy[q];
                 s_fx[q] = 0;
                 s_fy[q] = 0;
+                const float2 p_old = particle.p;
                 if (!((SB_BK_ABLATE & 2) && prm.time_step >= 0.0f)) sb_particle_finish<PLAIN>(prm, c, particle, fx, fy);
+                if (TRACK && i < (int)SB_BK_OWNP) { // (as sb_substep_tiled measures it: sqrt(2) x the larger component)
+                    const float ddx = particle.p.x - p_old.x, ddy = particle.p.y - p_old.y;
+                    const float m = fmaxf(sb_abs(ddx - track_cx), sb_abs(ddy - track_cy)) * 1.4142137f;
+                    moved_now = fmaxf(moved_now, m < 1.0e30f ? m : 1.0e30f); // (NaN reads as huge)
+                    if (i == 0 && tid == 0 && s == k_run) { // this tile's sample for the next launch's drift estimate
+                        __hip_atomic_store(&tr.dmax[tr.ntiles + 2u * tile], __float_as_uint(sb_abs(ddx) < 1.0e30f ? ddx : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&tr.dmax[tr.ntiles + 2u * tile + 1u], __float_as_uint(sb_abs(ddy) < 1.0e30f ? ddy : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 s_pos[q] = particle.p;
                 pv[i] = particle.v;
                 pa[i] = particle.a;
             }
         }
+        if (TRACK) moved_sum += moved_now;
         if (!(SB_BK_ABLATE & 32)) __syncthreads();
         nbl = __builtin_amdgcn_readfirstlane(nbl_next);
         npr = __builtin_amdgcn_readfirstlane(npr_next);
@@ -427,7 +460,10 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
             if (__builtin_expect(word[i] != bp.dummy_word, 1)) {
                 if (plastic_w) bs.target_w[b0 + j] = tg[i];
                 bs.last_w[b0 + j] = ls[i];
-                if ((brk >> i) & 1u) atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
+                if ((brk >> i) & 1u) {
+                    atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
+                    if (TRACK) __hip_atomic_store(tr.any_broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else {
                 // a beam removed by a delete pass keeps its last state, which still has to travel to the other buffer: load,
                 // wait and store all INSIDE this branch (the wait at the join of the conditional form ran on every beam and
@@ -442,6 +478,127 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     }
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
     if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
+    if (TRACK) {
+        __shared__ float s_moved[SB_BK_T / 64u];
+        float m = moved_sum < 1.0e30f ? moved_sum : 1.0e30f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((tid & 63u) == 0u) s_moved[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            float b = 0.0f;
+            for (uint32_t v = 0; v < SB_BK_T / 64u; v++) b = fmaxf(b, s_moved[v]);
+            __hip_atomic_store(&tr.dmax[tile], __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// after every tracked launch: the largest displacement sum of any tile joins the bound
+__global__ __launch_bounds__(1024) void k_hybrid_validate(const uint32_t *__restrict__ dmax, uint32_t ntiles, SbHybridCtl *q, uint32_t k,
+                                                          uint32_t *broken_new, uint32_t *broken_ok, uint32_t nwords)
+{
+    __shared__ float s_m[16], s_x[16], s_y[16];
+    __shared__ uint32_t s_ok;
+    if (__hip_atomic_load(&q->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    float m = 0.0f, sx = 0.0f, sy = 0.0f;
+    for (uint32_t i = threadIdx.x; i < ntiles; i += 1024u) {
+        m = fmaxf(m, __uint_as_float(__hip_atomic_load(&dmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        sx += __uint_as_float(__hip_atomic_load(&dmax[ntiles + 2u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        sy += __uint_as_float(__hip_atomic_load(&dmax[ntiles + 2u * i + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off, 64));
+        sx += __shfl_xor(sx, off, 64);
+        sy += __shfl_xor(sy, off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        s_m[threadIdx.x >> 6] = m;
+        s_x[threadIdx.x >> 6] = sx;
+        s_y[threadIdx.x >> 6] = sy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = 0.0f, tx = 0.0f, ty = 0.0f;
+        for (int v = 0; v < 16; v++) {
+            b = fmaxf(b, s_m[v]);
+            tx += s_x[v];
+            ty += s_y[v];
+        }
+        const float D = q->D + b;
+        const bool ok = D <= q->skin && q->done != q->fail_at; // (NaN-safe; fail_at: the forced roll-back of the tests)
+        s_ok = ok ? 1u : 0u;
+        if (!ok) {
+            __hip_atomic_store(&q->bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            q->D = D;
+            q->Cx += (float)k * q->cx; // (the drift the launch measured against ...)
+            q->Cy += (float)k * q->cy;
+            float mx = tx / (float)ntiles, my = ty / (float)ntiles; // (... and the one the next launch will: any estimate keeps the bound valid)
+            if (!(sb_abs(mx) < 1.0e30f) || !(sb_abs(my) < 1.0e30f)) mx = my = 0.0f;
+            __hip_atomic_store((uint32_t *)&q->cx, __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((uint32_t *)&q->cy, __float_as_uint(my), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q->done += 1u;
+            q->substeps += k;
+        }
+    }
+    // break flags the launch raised (almost never any): kept if the launch counts, dropped if not
+    if (__hip_atomic_load(&q->any_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __syncthreads();
+        const bool ok = s_ok != 0u;
+        for (uint32_t i = threadIdx.x; i < nwords; i += 1024u) {
+            const uint32_t bits = broken_new[i];
+            if (bits) {
+                if (ok) broken_ok[i] |= bits;
+                broken_new[i] = 0u;
+            }
+        }
+        if (threadIdx.x == 0) q->any_broken = 0u;
+    }
+}
+
+// beam state between the two device layouts of an SB_COLLIDE_GRID engine that can run blocked (sb_api.hip hybrid_step): the
+// tiled layout (one copy per tile that holds an endpoint) is where the state lives between API calls; the blocked layout
+// (one slot per beam) borrows it for a run of blocked launches
+__global__ __launch_bounds__(256) void k_hybrid_to_blocked(const float *__restrict__ t_target, const float *__restrict__ t_last,
+                                                           const uint32_t *__restrict__ copy_of_g, uint32_t nb, float *b_target,
+                                                           float *b_target_other, float *b_last)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= nb) return;
+    const uint32_t cpy = copy_of_g[g];
+    const float t = t_target[cpy];
+    b_target[g] = t;
+    b_target_other[g] = t; // (a tile that does not yield never stores its targets: both buffers must hold them)
+    b_last[g] = t_last[cpy];
+}
+__global__ __launch_bounds__(256) void k_hybrid_to_tiled(const float *__restrict__ b_target, const float *__restrict__ b_last,
+                                                         const float *__restrict__ b_strain, const float *__restrict__ b_stress,
+                                                         uint32_t *b_broken, const uint32_t *__restrict__ g_of_copy, uint32_t nc,
+                                                         float *t_target, float *t_last, float *t_strain, float *t_stress,
+                                                         uint32_t *t_broken, int aux)
+{
+    const uint32_t cpy = blockIdx.x * 256u + threadIdx.x;
+    if (cpy >= nc) return;
+    const uint32_t g = g_of_copy[cpy];
+    if (g == 0xFFFFFFFFu) return; // padding copy
+    t_target[cpy] = b_target[g];
+    t_last[cpy] = b_last[g];
+    if (aux) {
+        t_strain[cpy] = b_strain[g];
+        t_stress[cpy] = b_stress[g];
+    }
+    if ((b_broken[g >> 5] >> (g & 31u)) & 1u) atomicOr(&t_broken[cpy >> 5], 1u << (cpy & 31u));
+}
+// entries of beams the tiled layout's delete passes have removed since the blocked plan last looked
+__global__ __launch_bounds__(256) void k_hybrid_sync_dead(const uint32_t *__restrict__ t_pair, const uint32_t *__restrict__ copy_slot,
+                                                          uint32_t nc, const uint32_t *__restrict__ slot_e0,
+                                                          const uint32_t *__restrict__ slot_ent, uint32_t *ent_word, uint32_t dummy_word)
+{
+    const uint32_t cpy = blockIdx.x * 256u + threadIdx.x;
+    if (cpy >= nc || copy_slot[cpy] == 0xFFFFFFFFu || t_pair[cpy] != 0xFFFFFFFFu) return;
+    const uint32_t sl = copy_slot[cpy];
+    for (uint32_t en = slot_e0[sl]; en < slot_e0[sl + 1]; en++) ent_word[slot_ent[en]] = dummy_word;
 }
 
 // delete pass of the blocked layout: every entry of a flagged beam (the owner's and the halo copies in other
@@ -505,50 +662,98 @@ static void allow_large_lds(int device)
     if (device < 0 || device >= 64 || done[device]) return;
     done[device] = true;
     const int bytes = 100 * 1024;
-    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#define SB_ALLOW(A, PL, TR) (void)hipFuncSetAttribute((const void *)k_substep_blocked<1, A, PL, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+    SB_ALLOW(false, false, false); SB_ALLOW(false, true, false); SB_ALLOW(true, false, false); SB_ALLOW(true, true, false);
+    SB_ALLOW(false, false, true); SB_ALLOW(false, true, true); SB_ALLOW(true, false, true); SB_ALLOW(true, true, true);
+#undef SB_ALLOW
+    (void)hipGetLastError(); // (not sticky)
+}
+
+// one launch of k substeps on the blocked layout `bk` (the engine's own, or the one an SB_COLLIDE_GRID engine keeps beside
+// its tiled layout); flips the particle and beam-state buffers
+static void launch_one(sb_engine *e, SbBlockedDev &bk, uint32_t k, bool aux, bool track)
+{
+    SbBlockedPlan bp{bk.d_tile_p0, bk.d_tile_h0, bk.d_halo_idx, bk.d_ring_cnt, bk.d_tile_b0, bk.d_tile_e0, bk.d_tile_s0, bk.d_ent_word,
+                     bk.d_ent_state, bk.d_lvl_cnt, bk.d_tile_n0, bk.d_tile_nb, bk.d_ent_length, bk.d_mat, bk.ntiles, bk.K, bk.cap,
+                     bk.nmat, bk.dummy_word};
+    SbBlockedState bs{bk.d_target[bk.cur], bk.d_last[bk.cur], bk.d_target[bk.cur ^ 1u], bk.d_last[bk.cur ^ 1u], bk.d_strain, bk.d_stress,
+                      bk.d_broken, bk.d_plastic[bk.cur], bk.d_plastic[bk.cur ^ 1u]};
+    SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
+    SbTrack tr{bk.d_q, bk.d_dmax, bk.ntiles, bk.d_q ? &bk.d_q->any_broken : nullptr};
+    if (track) bs.broken = bk.d_broken_new; // (validated into bk.d_broken by k_hybrid_validate)
+#define SB_LAUNCH_B(M, A, PL, TR)                                                                                            \
+    k_substep_blocked<M, A, PL, TR><<<bk.ntiles, SB_BK_T, bk.lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,        \
+                                                                                    e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1], tr)
+#define SB_LAUNCH_BT(M, A, PL) do { if (track) SB_LAUNCH_B(M, A, PL, true); else SB_LAUNCH_B(M, A, PL, false); } while (0)
+#define SB_LAUNCH_BA(M, PL) do { if (aux) SB_LAUNCH_BT(M, true, PL); else SB_LAUNCH_BT(M, false, PL); } while (0)
+    // the constants of THIS launch (they ride in its kernarg): the reference's defaults take the plain particle phase
+    const bool plain = e->consts.drag_exp == 2.0f && e->consts.mouse_active == 0u;
+    if (bk.ntiles) {
+        if (bk.mat_mode == 2) {
+            if (plain) SB_LAUNCH_BA(2, true); else SB_LAUNCH_BA(2, false);
+        } else {
+            if (plain) SB_LAUNCH_BA(1, true); else SB_LAUNCH_BA(1, false);
+        }
+    }
+#undef SB_LAUNCH_BA
+#undef SB_LAUNCH_BT
+#undef SB_LAUNCH_B
+    e->cur ^= 1;
+    bk.cur ^= 1u;
+    e->substeps_done += k;
 }
 
 // n substeps as the launches sbk_split_call chooses; the last launch of a call also stores strain/stress when write_aux
 void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux)
 {
-    if (e->mat_mode == 1) allow_large_lds(e->device);
+    if (e->bk.mat_mode == 1) allow_large_lds(e->device);
     uint32_t k_hi = 0, n_hi = 0;
     sbk_split_call(n, e->bk.K, e->bk.fixed_depth, &k_hi, &n_hi);
-    SbBlockedPlan bp{e->bk.d_tile_p0, e->bk.d_tile_h0, e->bk.d_halo_idx, e->bk.d_ring_cnt, e->bk.d_tile_b0, e->bk.d_tile_e0,
-                     e->bk.d_tile_s0, e->bk.d_ent_word, e->bk.d_ent_state, e->bk.d_lvl_cnt, e->bk.d_tile_n0, e->bk.d_tile_nb,
-                     e->bk.d_ent_length, e->d_mat, e->ntiles, e->bk.K, e->bk.cap, e->nmat, e->bk.dummy_word};
     while (n) {
         const uint32_t k = n_hi ? k_hi : k_hi - 1u; // the deeper launches first
         if (n_hi) n_hi--;
-        const bool aux = write_aux && k == n;
-        SbBlockedState bs{e->bk.d_target[e->bk.cur], e->bk.d_last[e->bk.cur], e->bk.d_target[e->bk.cur ^ 1u],
-                          e->bk.d_last[e->bk.cur ^ 1u], e->beams.strain, e->beams.stress, e->d_broken, e->bk.d_plastic[e->bk.cur],
-                          e->bk.d_plastic[e->bk.cur ^ 1u]};
-        SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
-#define SB_LAUNCH_B(M, A, PL)                                                                                         \
-    k_substep_blocked<M, A, PL><<<e->ntiles, SB_BK_T, e->lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,  \
-                                                                                e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
-#define SB_LAUNCH_BA(M, PL) do { if (aux) SB_LAUNCH_B(M, true, PL); else SB_LAUNCH_B(M, false, PL); } while (0)
-        // the constants of THIS launch (they ride in its kernarg): the reference's defaults take the plain particle phase
-        const bool plain = e->consts.drag_exp == 2.0f && e->consts.mouse_active == 0u;
-        if (e->ntiles) {
-            if (e->mat_mode == 2) {
-                if (plain) SB_LAUNCH_BA(2, true); else SB_LAUNCH_BA(2, false);
-            } else {
-                if (plain) SB_LAUNCH_BA(1, true); else SB_LAUNCH_BA(1, false);
-            }
-        }
-#undef SB_LAUNCH_BA
-#undef SB_LAUNCH_B
-        e->cur ^= 1;
-        e->bk.cur ^= 1u;
+        launch_one(e, e->bk, k, write_aux && k == n, false);
         e->beams.target = e->bk.d_target[e->bk.cur]; // what read-back, halo pack/unpack and the next launch see
         e->beams.last = e->bk.d_last[e->bk.cur];
-        e->substeps_done += k;
         n -= k;
+    }
+}
+
+// ---- SB_COLLIDE_GRID engines with a blocked plan beside the tiled one (e->hy; sb_api.hip hybrid_step drives these)
+void sbk_hybrid_to_blocked(sb_engine *e)
+{
+    SbBlockedDev &h = e->hy;
+    const uint32_t B = h.nbeams;
+    if (!B) return;
+    if (h.synced_delete_gen != e->delete_gen) { // beams the tiled layout has removed since: their entries die here too
+        k_hybrid_sync_dead<<<cdiv_b(e->nbeam, 256), 256, 0, e->stream>>>(e->beams.pair, e->beams.slot, e->nbeam, h.d_slot_e0, h.d_slot_ent,
+                                                                        h.d_ent_word, h.dummy_word);
+        h.synced_delete_gen = e->delete_gen;
+    }
+    k_hybrid_to_blocked<<<cdiv_b(B, 256), 256, 0, e->stream>>>(e->beams.target, e->beams.last, h.d_copy_of_g, B, h.d_target[h.cur],
+                                                               h.d_target[h.cur ^ 1u], h.d_last[h.cur]);
+    (void)hipMemsetAsync(h.d_broken, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
+    (void)hipMemsetAsync(h.d_broken_new, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
+    // (the plastic flags stay as they are: they only ever go up, and a target that moved while the state lived in the tiled
+    // layout moved on BOTH of that layout's copies of a cut beam -- set them all, the simple and safe reading)
+    for (int b = 0; b < 2; b++) (void)hipMemsetAsync(h.d_plastic[b], 0x01, (size_t)std::max(h.ntiles, 1u) * 4, e->stream);
+}
+void sbk_hybrid_to_tiled(sb_engine *e, bool aux)
+{
+    SbBlockedDev &h = e->hy;
+    if (!e->nbeam) return;
+    k_hybrid_to_tiled<<<cdiv_b(e->nbeam, 256), 256, 0, e->stream>>>(h.d_target[h.cur], h.d_last[h.cur], h.d_strain, h.d_stress, h.d_broken,
+                                                                   h.d_g_of_copy, e->nbeam, e->beams.target, e->beams.last,
+                                                                   e->beams.strain, e->beams.stress, e->d_broken, aux ? 1 : 0);
+}
+// `count` launches of the depths in ks[], each followed by its validation; nothing here waits
+void sbk_hybrid_launch(sb_engine *e, const uint32_t *ks, uint32_t count, bool aux_last)
+{
+    SbBlockedDev &h = e->hy;
+    if (h.mat_mode == 1) allow_large_lds(e->device);
+    for (uint32_t i = 0; i < count; i++) {
+        launch_one(e, h, ks[i], aux_last && i + 1 == count, true);
+        k_hybrid_validate<<<1, 1024, 0, e->stream>>>(h.d_dmax, h.ntiles, h.d_q, ks[i], h.d_broken_new, h.d_broken, cdiv_b(h.nbeams, 32));
     }
 }
 

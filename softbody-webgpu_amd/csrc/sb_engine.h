@@ -49,6 +49,16 @@ struct SbParticleArrays {
 #define SB_BK_KPLAN 7u
 #define SB_BK_KLONG 6u
 
+// the hybrid's running state on the device (sb_api.hip hybrid_step)
+struct SbHybridCtl {
+    float D, Cx, Cy;     // the hash's displacement bound and accumulated drift, carried through the blocked launches
+    float cx, cy, skin;  // the drift every launch measures against; the budget
+    uint32_t bad, done;  // sticky: a launch went over the budget (its result is discarded); launches that stayed within it
+    uint32_t substeps;   // ... and the substeps they advanced
+    uint32_t any_broken; // the launch in flight flagged a beam (its flags wait in a mask of their own for the verdict)
+    uint32_t fail_at;    // tests: the launch with this number fails whatever it measured (0xFFFFFFFF: none)
+};
+
 // device side of the temporally blocked plan (sb_blocking.h, sb_blocked.hip)
 struct SbBlockedDev {
     uint32_t K = 0;           // substeps per launch; 0 = the engine is not running blocked
@@ -59,9 +69,26 @@ struct SbBlockedDev {
              *d_tile_e0 = nullptr, *d_tile_s0 = nullptr, *d_ent_word = nullptr, *d_ent_state = nullptr, *d_lvl_cnt = nullptr,
              *d_tile_n0 = nullptr, *d_tile_nb = nullptr, *d_slot_e0 = nullptr, *d_slot_ent = nullptr;
     float *d_ent_length = nullptr;
+    uint32_t *d_ent_word0 = nullptr; // d_ent_word as uploaded (delete passes turn entries into dummies; an upload that keeps the plan undoes that)
+    std::vector<uint32_t> h_beam_slot, h_tile_b0; // blocked beam -> mapping slot, beams per tile (host copies, for the same)
     float *d_target[2] = {nullptr, nullptr}, *d_last[2] = {nullptr, nullptr};
     uint32_t *d_plastic[2] = {nullptr, nullptr}; // per state buffer, per tile: 0 = every owned beam's target is still its rest length (sb_blocked.hip)
     bool pristine = false;    // as of the upload: no tile had a yielded beam (the traffic model leaves the targets out then)
+    // what a launch works on besides the plan (the engine's own arrays when the blocked layout is the engine's layout; arrays of
+    // its own when it sits beside the tiled layout of an SB_COLLIDE_GRID engine: e->hy)
+    float *d_mat = nullptr;   // [nmat][6]
+    uint32_t nmat = 0, mat_mode = 0, ntiles = 0, nbeams = 0;
+    size_t lds_bytes = 0;
+    float *d_strain = nullptr, *d_stress = nullptr;
+    uint32_t *d_broken = nullptr;
+    // hybrid only
+    uint32_t *d_broken_new = nullptr; // break flags of the tracked launch in flight
+    uint32_t *d_copy_of_g = nullptr, *d_g_of_copy = nullptr; // blocked beam -> a tiled copy of it; tiled copy -> blocked beam
+    SbHybridCtl *d_q = nullptr;
+    uint32_t *d_dmax = nullptr;       // per tile: largest displacement sum of the last tracked launch (float bits)
+    uint32_t synced_delete_gen = 0;   // delete passes of the tiled layout this plan has seen
+    uint32_t slow_chunk = 0, slow_left = 0; // substeps to run substep by substep before looking again whether the scene is quiet (doubles while it is not)
+    uint64_t launches_ok = 0, launches_failed = 0, substeps_blocked = 0;
     uint32_t k_long = 0;      // substeps per launch of a long call (what the traffic model prices)
     bool fixed_depth = false; // the caller named the depth (sb_options.block_substeps): every call runs in the fewest launches
     uint64_t entries = 0, halo_entries = 0, halo_particles = 0; // totals of the whole plan (depth K)
@@ -93,6 +120,12 @@ struct sb_engine {
     std::vector<uint32_t> h_pslot;   // internal particle -> mapping slot
     std::vector<uint32_t> h_copy_of_slot; // beam slot -> index of the copy read back for it
     SbHostBeams h_beams;      // static part of every active beam record, per slot
+    // what an upload of the same topology reuses (sb_api.hip rewrite_scene_state): copy / blocked beam -> mapping slot, the
+    // blocked plan's beams per tile, a pristine copy of the one device array delete passes write into
+    std::vector<uint32_t> h_slot_of_copy;
+    uint32_t *d_live0 = nullptr;     // entry words (blocked) / endpoint words (tiled) / first endpoints (atomic) as uploaded
+    size_t live_words = 0;
+    uint32_t uploads_kept = 0;       // uploads that kept the plan (sb_info "uploads_kept")
 
     // device state
     SbParticleArrays part[2]{};
@@ -131,6 +164,7 @@ struct sb_engine {
     size_t lds_bytes = 0;
     uint32_t *d_acc_flag[2] = {nullptr, nullptr}; // per particle buffer, per tile: 0 = every acc is zero
     SbBlockedDev bk;
+    SbBlockedDev hy;                  // SB_COLLIDE_GRID: a blocked plan BESIDE the tiled layout, for the stretches in which nothing is within reach (hy.K != 0: available)
     // beam word packing and material dictionary (tiled path)
     uint32_t lbits = 16;      // bits per tile-local endpoint index
     uint32_t mat_mode = 0;    // 0: per-copy parameter arrays; 1: table of (spring,damp,yield,limit) + per-copy length;
@@ -147,9 +181,12 @@ struct sb_engine {
     SbGridCtl *d_grid_ctl = nullptr;  // [2] rebuild decision state by substep parity (device resident: no host sync per substep)
     uint32_t *d_blk_max[2] = {};      // per workgroup of the particle kernel: largest displacement (float bits), by parity
     uint32_t *d_nl_count = nullptr, *d_nl = nullptr; // neighbour lists (SbGrid)
+    uint32_t *d_grid_nonempty = nullptr; // sbk_launch_lists_nonempty: 0 = every neighbour list of the hash in force is empty
     uint32_t *d_grid_outside = nullptr; // particles the hash build in progress found outside its frame (zero between builds)
     uint32_t *d_grid_done = nullptr;  // workgroups of the hash build in progress that have finished (zero between builds)
     uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
+    SbGridCtl grid_ctl0[2]{};         // the decision state a fresh upload starts from
+    size_t grid_heads = 0, grid_slots = 0; // entries of d_head, of each d_blk_max
     uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)
     // pinned staging of uploads and read-backs (sb_api.hip: stage_*): two chunks, filled / drained by several host threads while
     // the other one is on the wire (hipMemcpy from pageable memory stages through ONE thread: ~5 GB/s)
@@ -167,6 +204,7 @@ struct sb_engine {
 // sb_kernels.hip
 void sbk_launch_substep(sb_engine *e, bool write_aux);
 void sbk_launch_delete(sb_engine *e);
+void sbk_launch_lists_nonempty(sb_engine *e); // e->d_grid_nonempty = any neighbour list not empty (hybrid look)
 void sbk_launch_halo_clear_ghost_flags(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float *src);
@@ -175,3 +213,6 @@ void sbk_launch_peer_exchange(sb_engine *e);
 void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux);
 uint32_t sbk_split_call(uint32_t n, uint32_t kmax, bool fewest, uint32_t *first, uint32_t *n_first); // launches: n_first of depth first, the rest first - 1
 void sbk_launch_delete_blocked(sb_engine *e);
+void sbk_hybrid_to_blocked(sb_engine *e);
+void sbk_hybrid_to_tiled(sb_engine *e, bool aux);
+void sbk_hybrid_launch(sb_engine *e, const uint32_t *ks, uint32_t count, bool aux_last);

@@ -807,6 +807,22 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     e->substeps_done++;
 }
 
+// Is anybody on anybody's neighbour list?  Asked by the host between launches (sb_api.hip hybrid_substeps), never on the
+// substep path: the word is cleared, then set by the first wave that finds a count that is not zero (SB_NL_OVERFLOW counts).
+__global__ __launch_bounds__(SB_BLOCK) void k_lists_nonempty(const uint32_t *__restrict__ nl_count, uint32_t P, uint32_t *out)
+{
+    bool any = false;
+    for (uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x; i < P; i += gridDim.x * SB_BLOCK) any |= nl_count[i] != 0u;
+    if (__builtin_amdgcn_ballot_w64(any) != 0ull && (threadIdx.x & 63u) == 0u && SB_AGENT_LOAD(out) == 0u) SB_AGENT_STORE(out, 1u);
+}
+
+void sbk_launch_lists_nonempty(sb_engine *e)
+{
+    (void)hipMemsetAsync(e->d_grid_nonempty, 0, 4, e->stream);
+    k_lists_nonempty<<<std::min(std::max(cdiv(e->P, SB_BLOCK * 4u), 1u), 2048u), SB_BLOCK, 0, e->stream>>>(e->grid.nl_count, e->P,
+                                                                                                            e->d_grid_nonempty);
+}
+
 void sbk_launch_delete(sb_engine *e)
 {
     if (!e->nbeam) return;
