@@ -388,6 +388,12 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     build_material_dictionary(md, hb, 1u << (32u - 2u * SB_BK_LBITS));
     bool plain_yield = true; // sb_beam_group applies sign(strain) as a copied sign bit, exact for yield_strain >= 0
     for (size_t r = 0; r < md.table.size(); r += 6) plain_yield = plain_yield && md.table[r + 3] >= 0.0f;
+    // ... and the force scale early, as a factor of spring and damp: exact while they are zero or ordinary numbers (SbBeamMat::sd)
+    for (size_t r = 0; r < md.table.size(); r += 6)
+        for (int f = 1; f <= 2; f++) {
+            const float v = std::fabs(md.table[r + f]);
+            plain_yield = plain_yield && (v == 0.0f || (v >= SB_BK_SD_MIN && v <= SB_BK_SD_MAX));
+        }
     if (md.mode == 0 || !plain_yield) {
         blockK = 0;
         return SB_OK;

@@ -254,8 +254,8 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         float *d = s_mat + SB_BK_ROW * i;
         d[0] = h[0];
         d[1] = h[5];
-        d[2] = h[1];
-        d[3] = h[2];
+        d[2] = h[1] * 65536.0f; // (spring, damp) times the force scale: SbBeamMat::sd
+        d[3] = h[2] * 65536.0f;
         d[4] = h[3];
         d[5] = h[3] * h[0]; // yield_strain * length, the first product of compute.wgsl:115
         d[6] = h[0] * h[4]; // length * strain_break_limit, :117
@@ -301,7 +301,8 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                 float2 qa[SB_BK_G], qb[SB_BK_G];
                 SbBeamMat mt[SB_BK_G];
                 uint32_t la[SB_BK_G], lb[SB_BK_G];
-                float t_in[SB_BK_G], l_in[SB_BK_G], strain[SB_BK_G], stress[SB_BK_G];
+                float t_in[SB_BK_G], l_in[SB_BK_G];
+                float spring_s[SB_BK_G], damp_s[SB_BK_G]; // (times the force scale: SbBeamMat::sd)
                 int32_t fa[SB_BK_G][2], fb[SB_BK_G][2];
                 bool broken[SB_BK_G];
 #pragma unroll
@@ -314,9 +315,10 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                     const float4 *row = (const float4 *)(s_mat + SB_BK_ROW * (word[i] >> (2u * SB_BK_LBITS)));
                     qa[u] = s_pos[la[u]];
                     qb[u] = s_pos[lb[u]];
-                    const float4 r0 = row[0], r1 = row[1]; // length, 1/length, spring, damp | yield, yield*length, length*limit, limit
-                    mt[u].spring = r0.z;
-                    mt[u].damp = r0.w;
+                    const float4 r0 = row[0], r1 = row[1]; // length, 1/length, spring', damp' | yield, yield*length, length*limit, limit
+                    mt[u].sd = sb_v2{r0.z, r0.w};
+                    spring_s[u] = r0.z;
+                    damp_s[u] = r0.w;
                     mt[u].yield_strain = r1.x;
                     if (MAT == 2) {
                         mt[u].length = r0.x;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                         asm volatile("" : "+v"(j)); // (or the store addresses of a thread are hoisted out of the substep loop: 48 VGPRs)
                         if (i < (int)SB_BK_OWNB && j < n_ownb && word[i] != bp.dummy_word) {
                             const float len = sb_beam_length(qa[u], qb[u]);
-                            const float force_mag = (tg[i] - len) * mt[u].spring + (ls[i] - len) * mt[u].damp; // :110
+                            const float force_mag = (tg[i] - len) * (spring_s[u] * 0x1p-16f) + (ls[i] - len) * (damp_s[u] * 0x1p-16f); // :110 (the scaling is exact)
                             const float strain_v = (len - tg[i]) * mt[u].inv_length;                           // :112
                             bs.stress[b0 + j] = force_mag * (1.0f / 20.0f);                                    // :122
                             bs.strain[b0 + j] = sb_div(sb_abs(strain_v), mt[u].yield_strain);                  // :123
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                     }
                 }
                 bool mirrored;
-                sb_beam_group<SB_BK_G, false>(qa, qb, mt, t_in, l_in, fa, fb, mirrored, broken, strain, stress);
+                sb_beam_group<SB_BK_G>(qa, qb, mt, t_in, l_in, fa, fb, mirrored, broken);
 #pragma unroll
                 for (int u = 0; u < SB_BK_G; u++) {
                     const int i = i0 + u;

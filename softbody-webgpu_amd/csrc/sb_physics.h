@@ -260,8 +260,23 @@ SB_DEV float sb_beam_length(float2 pa, float2 pb)
 // sign(strain) enters :115 only as a factor of +-1 (exact) when |strain| > yield_strain >= 0, so it is applied as a
 // copied sign bit; the host routes scenes with a negative or NaN yield_strain to the single-substep kernel, where
 // sign() is spelled out.
+// Two floats in a register pair: + - * on them are ONE v_pk_add_f32 / v_pk_mul_f32 (each half rounded exactly as the scalar
+// instruction rounds it; with -ffp-contract=off nothing is fused), and a scalar operand is broadcast by the instruction's
+// operand select, not by a copy.  The blocked kernel's beam phase is bound by the vector ALU's issue rate, and half of a
+// beam's arithmetic comes in such pairs: (x, y), and (target - len, last - len) against (spring, damp).
+typedef float sb_v2 __attribute__((ext_vector_type(2)));
+// `sd` = (spring, damp) TIMES the force scale 65536 (compute.wgsl:70): the reference scales each force component last,
+// (force_mag * n) * 65536; a power of two commutes with every rounding on the way there -- (target - len) * spring, the sum,
+// the product with n -- as long as no intermediate is subnormal or overflows.  The host only lets scenes in whose every spring
+// and damp is zero or between 2^-50 and 2^100 in magnitude (SB_BK_SD_MIN / MAX: with lengths inside the sqrt gate no product
+// can then be subnormal); an overflow shows up as a value the `mirrored` gate refuses, and that branch evaluates in the
+// reference's order.  One packed multiplication less per beam.
+#define SB_BK_SD_MIN 0x1p-50f
+#define SB_BK_SD_MAX 0x1p100f
 struct SbBeamMat {
-    float length, inv_length, spring, damp, yield_strain, yl, ll;
+    float length, inv_length;
+    sb_v2 sd; // (spring, damp) * 65536
+    float yield_strain, yl, ll;
 };
 // max(|a|, |b|, |c|) in one instruction (source modifiers; spelled as asm so that no canonicalising copies appear)
 SB_DEV float sb_max3_abs(float a, float b, float c)
@@ -270,27 +285,33 @@ SB_DEV float sb_max3_abs(float a, float b, float c)
     asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// target_length and last_length of each beam go in and out.
 // Forces: endpoint B gets i32(+f*s) (:129-130), endpoint A gets i32(-f*s) (:127-128).  The conversion truncates toward zero,
 // so the two are exact negatives of each other -- unless it saturates (|f*s| >= 2^31: INT_MAX on one side, INT_MIN on the
 // other) .  `mirrored` (wave-uniform) says that no lane of the wave is anywhere near that: the caller then SUBTRACTS fb from
 // A's sums (ds_sub) and fa is not computed at all -- two conversions (each the price of two plain instructions) for three
 // instructions of gate per group.  NaN converts to 0 on both sides and passes the gate as what it is: harmless.
-template <int G, bool AUX>
-SB_DEV void sb_beam_group(const float2 (&pa)[G], const float2 (&pb)[G], const SbBeamMat (&m)[G], float (&target)[G],
-                          float (&last)[G], int32_t (&fa)[G][2], int32_t (&fb)[G][2], bool &mirrored, bool (&broken)[G],
-                          float (&strain_out)[G], float (&stress_out)[G])
+// Plastic yield (:113-116) is rare: the comparison is made for every beam, the new target only computed when some lane of the
+// wave needs it (the comparison's lane mask IS the ballot: the test costs scalar instructions only).
+template <int G>
+SB_DEV void sb_beam_group(const float2 (&pa)[G], const float2 (&pb)[G], const SbBeamMat (&m)[G], float (&target)[G], float (&last)[G],
+                          int32_t (&fa)[G][2], int32_t (&fb)[G][2], bool &mirrored, bool (&broken)[G])
 {
+    sb_v2 tl[G]; // (target_length, last_length): the caller's two registers usually ARE a pair
+#pragma unroll
+    for (int u = 0; u < G; u++) tl[u] = sb_v2{target[u], last[u]};
     const float particle_force_scale = 65536.0f; // :70
-    const float beam_stress_scale = 1.0f / 20.0f; // :71
-    float dx[G], dy[G], len2[G], len[G], inv_len[G], fsx[G], fsy[G];
+    sb_v2 d[G], fs[G];
+    float len2[G], len[G], inv_len[G], strain[G];
     // the gate as an OR of lane masks: each comparison lands in a scalar register pair and the branch tests their union
     // (a bool carried through && and then balloted went through a VGPR and back: two vector instructions per group)
     unsigned long long outside = 0ull;
 #pragma unroll
     for (int u = 0; u < G; u++) {
-        dx[u] = pb[u].x - pa[u].x; // :103
-        dy[u] = pb[u].y - pa[u].y;
-        len2[u] = dx[u] * dx[u] + dy[u] * dy[u];
+        const sb_v2 a = {pa[u].x, pa[u].y}, b = {pb[u].x, pb[u].y};
+        d[u] = b - a; // :103
+        const sb_v2 sq = d[u] * d[u];
+        len2[u] = sq.x + sq.y;
         outside |= __builtin_amdgcn_ballot_w64(!(len2[u] >= 0x1p-90f)) | __builtin_amdgcn_ballot_w64(!(len2[u] <= 0x1p90f));
     }
     if (outside == 0ull) {
@@ -303,43 +324,54 @@ SB_DEV void sb_beam_group(const float2 (&pa)[G], const float2 (&pb)[G], const Sb
         for (int u = 0; u < G; u++) {
             const float len0 = sb_sqrt(len2[u]);
             const bool degenerate = len0 == 0.0f; // :104-107
-            dx[u] = degenerate ? 0.0f : dx[u];
-            dy[u] = degenerate ? -1.0e-10f : dy[u];
+            d[u].x = degenerate ? 0.0f : d[u].x;
+            d[u].y = degenerate ? -1.0e-10f : d[u].y;
             len[u] = degenerate ? sb_length(0.0f, -1.0e-10f) : len0;
             inv_len[u] = sb_div(1.0f, len[u]);
         }
     }
+    unsigned long long yields = 0ull;
 #pragma unroll
     for (int u = 0; u < G; u++) {
-        const float force_mag = (target[u] - len[u]) * m[u].spring + (last[u] - len[u]) * m[u].damp; // :110
-        const float nx = dx[u] * inv_len[u], ny = dy[u] * inv_len[u];
-        const float sx = force_mag * nx * particle_force_scale, sy = force_mag * ny * particle_force_scale; // :111, :127-130
-        const float strain = (len[u] - target[u]) * m[u].inv_length; // :112
-        const float signed_yl = m[u].yl * __uint_as_float((__float_as_uint(strain) & 0x80000000u) | 0x3f800000u); // * (+-1)
-        const float yielded_target = len[u] - signed_yl; // :115
-        if (AUX) {
-            stress_out[u] = force_mag * beam_stress_scale;                  // :122
-            strain_out[u] = sb_div(sb_abs(strain), m[u].yield_strain);      // :123
-        }
-        target[u] = (sb_abs(strain) > m[u].yield_strain) ? yielded_target : target[u]; // :113-116
-        broken[u] = sb_abs(len[u] - m[u].length) > m[u].ll;                             // :117
-        last[u] = len[u];                                                              // :124
-        fb[u][0] = sb_f32_to_i32(sx);
-        fb[u][1] = sb_f32_to_i32(sy);
-        fsx[u] = sx;
-        fsy[u] = sy;
+        const sb_v2 e = tl[u] - len[u];    // (target - len, last - len)
+        const sb_v2 w = e * m[u].sd;       // ... * (spring, damp) * 65536
+        const float force_scaled = w.x + w.y; // :110, times the force scale
+        const sb_v2 n = d[u] * inv_len[u];
+        fs[u] = n * force_scaled;                   // :111, :127-130: (force_mag * n) * scale, per component (see SbBeamMat::sd)
+        strain[u] = -e.x * m[u].inv_length;         // :112 (len - target is -(target - len), exactly)
+        yields |= __builtin_amdgcn_ballot_w64(sb_abs(strain[u]) > m[u].yield_strain);
+        broken[u] = sb_abs(len[u] - m[u].length) > m[u].ll; // :117
+        fb[u][0] = sb_f32_to_i32(fs[u].x);
+        fb[u][1] = sb_f32_to_i32(fs[u].y);
     }
-    float big = sb_max3_abs(fsx[0], fsy[0], fsx[G - 1]);
+    float big = sb_max3_abs(fs[0].x, fs[0].y, fs[G - 1].x);
 #pragma unroll
-    for (int u = 1; u < G; u++) big = sb_max3_abs(big, fsx[u], fsy[u]); // (the max of non-negative numbers: |big| = big)
-    mirrored = __builtin_amdgcn_ballot_w64(!(big < 0x1p30f)) == 0ull;   // (NaN operands drop out of v_max3: see above)
-    if (!mirrored) {
+    for (int u = 1; u < G; u++) big = sb_max3_abs(big, fs[u].x, fs[u].y); // (the max of non-negative numbers: |big| = big)
+    mirrored = __builtin_amdgcn_ballot_w64(!(big < 0x1p30f)) == 0ull;     // (NaN operands drop out of v_max3: see above)
+    if (!mirrored) { // some lane is huge, infinite -- or only looks so because the scale was applied early: the reference's own order
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            fa[u][0] = sb_f32_to_i32_neg(fsx[u]);
-            fa[u][1] = sb_f32_to_i32_neg(fsy[u]);
+            const sb_v2 e = tl[u] - len[u];
+            const sb_v2 w = e * (m[u].sd * 0x1p-16f); // (spring, damp) themselves: the scaling was exact
+            const float force_mag = w.x + w.y;
+            const sb_v2 n = d[u] * inv_len[u];
+            const sb_v2 f = n * force_mag * particle_force_scale;
+            fb[u][0] = sb_f32_to_i32(f.x);
+            fb[u][1] = sb_f32_to_i32(f.y);
+            fa[u][0] = sb_f32_to_i32_neg(f.x);
+            fa[u][1] = sb_f32_to_i32_neg(f.y);
         }
     }
+    if (__builtin_expect(yields != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const float signed_yl = m[u].yl * __uint_as_float((__float_as_uint(strain[u]) & 0x80000000u) | 0x3f800000u); // * (+-1)
+            const float yielded_target = len[u] - signed_yl;                                                              // :115
+            target[u] = (sb_abs(strain[u]) > m[u].yield_strain) ? yielded_target : target[u];                             // :113-116
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) last[u] = len[u]; // :124
 }
 
 // ---------------------------------------------------------------- particle (compute.wgsl:139-201)
