@@ -84,8 +84,12 @@ typedef struct sb_options {
                               * drift) since the last build.  0 = default: adaptive, starting at 0.4 r and
                               * doubling up to 1.6 r while hashes last 2 substeps or less; > 0 = that skin,
                               * fixed; negative = rebuild every substep */
-    uint32_t block_substeps; /* SB_PATH_TILED with SB_COLLIDE_OFF: substeps one launch advances out of LDS and
-                              * registers (temporal blocking over beam-hop rings; same bits as single substeps).
+    uint32_t block_substeps; /* SB_PATH_TILED: substeps one launch advances out of LDS and registers (temporal
+                              * blocking over beam-hop rings; same bits as single substeps).  With SB_COLLIDE_OFF
+                              * always; with SB_COLLIDE_GRID for the stretches of a run in which every neighbour
+                              * list of the spatial hash is empty (the collision loop is then a no-op; the engine
+                              * tracks what the particles move and redoes, substep by substep, a launch that used
+                              * up the hash's skin).
                               * 0 = default: a plan 7 substeps deep, each call cut into the cheapest balanced
                               * launches (long calls 6 per launch, 20 substeps as 7 + 7 + 6); N > 1 = every call in
                               * the fewest launches of at most N (at most 8); 1 = one launch per substep.  Lowered
@@ -108,7 +112,11 @@ sb_status sb_destroy(sb_engine *e);
  * (-> buffer A) and beam data; zeroes the force accumulators, the delete mask and buffer B.
  * Buffers are the BufferMapper ArrayBuffers (engineMapping.ts:342-345) at FULL capacity:
  * metadata 112 B, mapping (max_particles+max_beams) entries, particles max_particles*24 B,
- * beams max_beams*stride B; the *_bytes arguments are checked against that. */
+ * beams max_beams*stride B; the *_bytes arguments are checked against that.
+ * An upload with the topology of the scene already on the device (same counts and mapping, every beam between the same
+ * two particles with the same rest length and material; no ghost zones configured) keeps the engine's plan and only moves
+ * state -- about a tenth of the time of an upload that plans (sb_get_info "uploads_kept" counts them); the results are
+ * those of a fresh engine either way. */
 sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_bytes,
                            const void *mapping, size_t mapping_bytes,
                            const void *particles, size_t particles_bytes,

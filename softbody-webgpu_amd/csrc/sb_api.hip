@@ -401,6 +401,7 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
     tm.mark("  material dictionary");
     SbBlockedDev &k = hybrid ? e->hy : e->bk;
     k.K = blockK;
+    k.plan_K = bl.K;
     k.cap = bl.max_region;
     k.dummy_word = (SB_BK_MAXP * SB_BK_T) | ((SB_BK_MAXP * SB_BK_T + 1u) << SB_BK_LBITS); // the two dummy LDS records, material row 0
     k.cur = 0;
@@ -926,8 +927,9 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         if (want_blocked) {
             // the plan is made as deep as asked for (default SB_BK_KPLAN) while every tile's region still fits the kernel's
             // per-thread register arrays and 12-bit local indices.  One breadth-first search to the depth asked for tells the
-            // region and entry sizes of EVERY smaller depth (they are prefixes), so a plan that does not fit is re-made once, at
-            // the deepest depth that does -- not once per candidate (a dense scene used to pay up to six plan builds per upload)
+            // region and entry sizes of EVERY smaller depth (they are prefixes) -- and a launch of k substeps only ever loads the
+            // depth-k prefix of the plan, so a plan that does not fit at full depth is kept as it is and the launches stay at the
+            // deepest depth that does (r02 re-made the plan for that depth: 65 ms per million particles; before that once per candidate)
             // (by class: the kernel keeps own and halo items in slots of their own, sb_blocked.hip)
             auto fits = [&](uint32_t d) {
                 return bl.max_own <= SB_BK_OWNP * SB_BK_T && bl.halo_at[d] <= SB_BK_HALOP * SB_BK_T && bl.max_ownb <= SB_BK_OWNB * SB_BK_T &&
@@ -943,12 +945,11 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
                 sb_build_blocking(bl, px, py, hb, target, blockK);
             }
             plan_target = target;
-            if (!fits(blockK)) {
+            if (!fits(blockK)) { // the plan stays (a launch of k substeps loads the depth-k prefix of it): launches just stay shallower
                 uint32_t fit = 0;
                 for (uint32_t d = 1; d < blockK; d++)
                     if (fits(d)) fit = d;
                 blockK = fit;
-                if (blockK) sb_build_blocking(bl, px, py, hb, target, blockK);
             }
         }
         if (blockK) {
@@ -1252,7 +1253,6 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
                 for (uint32_t d = 2; d < hk; d++)
                     if (fits(d)) fit = d;
                 hk = fit;
-                if (hk) sb_build_blocking(hbl, px, py, hb, tile_target_used, hk);
             }
             // the two plans must agree on the particle order and on the tiles (same bisection of the same positions)
             if (hk && hbl.order == tl.order && hbl.tile_p0 == tl.tile_p0) {

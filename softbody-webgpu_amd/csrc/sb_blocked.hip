@@ -676,7 +676,7 @@ static void allow_large_lds(int device)
 static void launch_one(sb_engine *e, SbBlockedDev &bk, uint32_t k, bool aux, bool track)
 {
     SbBlockedPlan bp{bk.d_tile_p0, bk.d_tile_h0, bk.d_halo_idx, bk.d_ring_cnt, bk.d_tile_b0, bk.d_tile_e0, bk.d_tile_s0, bk.d_ent_word,
-                     bk.d_ent_state, bk.d_lvl_cnt, bk.d_tile_n0, bk.d_tile_nb, bk.d_ent_length, bk.d_mat, bk.ntiles, bk.K, bk.cap,
+                     bk.d_ent_state, bk.d_lvl_cnt, bk.d_tile_n0, bk.d_tile_nb, bk.d_ent_length, bk.d_mat, bk.ntiles, bk.plan_K, bk.cap,
                      bk.nmat, bk.dummy_word};
     SbBlockedState bs{bk.d_target[bk.cur], bk.d_last[bk.cur], bk.d_target[bk.cur ^ 1u], bk.d_last[bk.cur ^ 1u], bk.d_strain, bk.d_stress,
                       bk.d_broken, bk.d_plastic[bk.cur], bk.d_plastic[bk.cur ^ 1u]};

@@ -61,7 +61,8 @@ struct SbHybridCtl {
 
 // device side of the temporally blocked plan (sb_blocking.h, sb_blocked.hip)
 struct SbBlockedDev {
-    uint32_t K = 0;           // substeps per launch; 0 = the engine is not running blocked
+    uint32_t K = 0;           // most substeps a launch may advance (the deepest prefix of the plan that fits the kernel's slots); 0 = the engine is not running blocked
+    uint32_t plan_K = 0;      // depth the plan was made for (the stride of ring_cnt / lvl_cnt); a launch of k <= K loads the depth-k prefix only
     uint32_t cap = 0;         // region capacity = local index of the first dummy endpoint
     uint32_t dummy_word = 0;  // entry word of dead and padding entries
     uint32_t cur = 0;         // which beam-state buffer holds the current state

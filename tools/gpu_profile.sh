@@ -1,15 +1,20 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): GPU tests, the default bench, rocprofv3 kernel trace + PMC passes.
-# Usage: tools/gpu_profile.sh <round-tag>      (then: python tools/summarize_profiles.py <round-tag>)
+# Usage: tools/gpu_profile.sh <round-tag> [tests|prof|bench|all]      (then: python tools/summarize_profiles.py <round-tag>)
+# (the three parts fit one 20-minute gpurun call each; "all" is for a box without that limit)
 # Every rocprofv3 run has the program itself after `--`; --pmc passes carry --kernel-trace only.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
+PART=${2:-all}
 OUT=$PWD/gpurun_out/$TAG
 ROOT=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ $PART = tests ] || [ $PART = all ]; then
 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 tail -3 $OUT/pytest_gpu.log
+fi
+if [ $PART = prof ] || [ $PART = all ]; then
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo bench failed; tail -5 $OUT/bench.err; exit 1; }
 cut -c1-300 $OUT/bench.json
 BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra"
@@ -36,9 +41,14 @@ prof trace_cfg3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 --
 prof pmc_fetch_cfg3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_cfg3 -- $CFG3
 prof pmc_write_cfg3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_cfg3 -- $CFG3
 cd $ROOT
+fi
+if [ $PART = bench ] || [ $PART = all ]; then
 python3 bench.py --config3 --no-cpu-baseline > $OUT/bench_config3.json 2>/dev/null || echo "config3 bench failed"
 python3 bench.py --block-substeps 1 --no-cpu-baseline --no-extra > $OUT/bench_single_substep.json 2>/dev/null || echo "k=1 bench failed"
 python3 bench.py --collisions grid --no-cpu-baseline --no-extra > $OUT/bench_grid.json 2>/dev/null || echo "grid bench failed"
+SB_HYBRID=0 python3 bench.py --collisions grid --no-cpu-baseline --no-extra > $OUT/bench_grid_no_hybrid.json 2>/dev/null || echo "grid bench (no hybrid) failed"
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_protocol.json 2>/dev/null || echo "driver-protocol bench failed"
+python3 bench.py --rest-lengths current --no-cpu-baseline --no-extra > $OUT/bench_rest_lengths.json 2>/dev/null || echo "mode-1 bench failed"
 python3 bench.py --lattice-on-floor --no-cpu-baseline --no-extra > $OUT/bench_config3_contacts.json 2>/dev/null || echo "lattice-on-floor bench failed"
 python3 bench.py --soup --no-cpu-baseline > $OUT/bench_soup.json 2>/dev/null || echo "soup bench failed"
 python3 tools/config3_contacts_check.py 2>/dev/null | grep -v "amdgpu.ids" > $OUT/config3_contacts_check.txt || echo "config3 check failed"
@@ -51,7 +61,9 @@ python3 bench.py --no-cpu-baseline --no-extra --width 4000 --height 4000 --steps
 # and the whole N=2 bench code path with both ranks on this card, started bare (rehearsal, not a measurement)
 python3 tools/exchange_cost.py 2>/dev/null | grep "^depth" > $OUT/exchange_cost.txt || echo "exchange cost probe failed"
 python3 bench.py --gpus 2 --rehearse-one-gpu --steps 480 --warmup 48 2>/dev/null > $OUT/rehearse_2ranks.json || echo "rehearsal failed"
+python3 bench.py --gpus 2 --rehearse-one-gpu --steps 20 --warmup 5 2>/dev/null > $OUT/rehearse_2ranks_driver_protocol.json || echo "rehearsal (driver protocol) failed"
 node softbody-webgpu_amd/host/bench.js > $OUT/node_bench.json 2> $OUT/node_bench.err || echo "node bench failed"
 SB_UPLOAD_TIMING=1 python3 tools/upload_timing.py 2>&1 | grep -v "amdgpu.ids" > $OUT/upload_timing.txt || echo "upload timing failed"
+fi
 find $OUT -name "*.csv" | wc -l
 du -sh $OUT

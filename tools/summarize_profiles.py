@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 if not os.path.isdir(src) or not glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
@@ -69,7 +69,10 @@ for name, out in (("bench_config3.json", "%s_bench_config3.json"), ("bench_singl
                   ("node_bench.json", "%s_node_bench.json"), ("cfg4_share.json", "%s_cfg4_share.json"),
                   ("cfg5_share.json", "%s_cfg5_share.json"),
                   ("bench_config3_contacts.json", "%s_bench_config3_lattice_on_floor.json"),
-                  ("bench_soup.json", "%s_bench_soup.json"), ("config3_contacts_check.txt", "%s_config3_contacts_check.txt")):
+                  ("bench_soup.json", "%s_bench_soup.json"), ("config3_contacts_check.txt", "%s_config3_contacts_check.txt"),
+                  ("bench_grid_no_hybrid.json", "%s_bench_grid_no_hybrid.json"), ("bench_driver_protocol.json", "%s_bench_driver_protocol.json"),
+                  ("bench_rest_lengths.json", "%s_bench_rest_lengths.json"),
+                  ("rehearse_2ranks_driver_protocol.json", "%s_rehearse_2ranks_one_gpu_driver_protocol.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, out % tag))
