@@ -646,6 +646,29 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(SbParticleArrays c, SbBe
     }
 }
 
+// What a refresh may do to the per-tile promises: a ghost particle that arrives with an acceleration breaks
+// "every acceleration of this tile is zero", a ghost beam whose target arrives changed (its owner's copy yielded) breaks "no beam
+// of this tile has ever yielded" -- for THAT tile (found by bisection of the tile tables; both events are rare), not for all of
+// them as three memsets per refresh used to say.  `flags.force`: the spatial hash rebins after a refresh (ghosts jumped).
+struct SbHaloFlags {
+    uint32_t *acc_flag;          // the current particle buffer's flags (nullptr: no tiles)
+    const uint32_t *tile_p0;     // [ntiles + 1]
+    uint32_t ntiles;
+    uint32_t *plastic0, *plastic1; // blocked layout only (else nullptr), with
+    const uint32_t *tile_b0;     // its beams per tile
+    uint32_t *force0, *force1;   // SbGridCtl::force of both parities (nullptr without a hash)
+};
+SB_DEV uint32_t sb_range_of(const uint32_t *__restrict__ first, uint32_t n, uint32_t i) // largest t < n with first[t] <= i
+{
+    uint32_t lo = 0u, hi = n;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (first[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
 // packed float buffer -> ghost lists (every device copy of a ghost beam is refreshed)
 __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, SbBeamArrays b,
                                                           const uint32_t *__restrict__ plist,
@@ -653,21 +676,33 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, Sb
                                                           const uint2 *__restrict__ blist,
                                                           const uint32_t *__restrict__ boff, uint32_t nbc,
                                                           const float *__restrict__ src, uint32_t *broken,
-                                                          const uint32_t *__restrict__ dead_gen)
+                                                          const uint32_t *__restrict__ dead_gen, SbHaloFlags flags)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
+    if (k == 0u && flags.force0) {
+        SB_AGENT_STORE(flags.force0, 1u);
+        SB_AGENT_STORE(flags.force1, 1u);
+    }
     if (k < np) {
         uint32_t i = plist[k];
         const float2 *in = (const float2 *)(src + poff[k]);
+        const float2 a = in[2];
         c.pos[i] = in[0];
         c.vel[i] = in[1];
-        c.acc[i] = in[2];
+        c.acc[i] = a;
+        if (flags.acc_flag && ((__float_as_uint(a.x) | __float_as_uint(a.y)) != 0u)) // (-0.0 counts, as in the substep kernels)
+            SB_AGENT_STORE(&flags.acc_flag[sb_range_of(flags.tile_p0, flags.ntiles, i)], 1u);
     } else if (k < np + nbc) {
         uint2 e = blist[k - np];
         float2 tl = *(const float2 *)(src + boff[e.y]);
         if (__float_as_uint(tl.y) == SB_HALO_DEAD) { // removed by its owner: flag this copy for sb_halo_delete_ghosts
             if (dead_gen[b.slot[e.x]] == 0u) atomicOr(&broken[e.x >> 5], 1u << (e.x & 31u));
         } else {
+            if (flags.plastic0 && __float_as_uint(b.target[e.x]) != __float_as_uint(tl.x)) {
+                const uint32_t t = sb_range_of(flags.tile_b0, flags.ntiles, e.x);
+                SB_AGENT_STORE(&flags.plastic0[t], 1u);
+                SB_AGENT_STORE(&flags.plastic1[t], 1u);
+            }
             b.target[e.x] = tl.x;
             b.last[e.x] = tl.y;
         }
@@ -849,18 +884,24 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
 {
     uint32_t n = e->n_ghost_p + e->n_ghost_b_copies;
     if (!n) return;
+    SbHaloFlags flags{};
+    if (e->ntiles) {
+        flags.acc_flag = e->d_acc_flag[e->cur];
+        flags.tile_p0 = e->bk.K ? e->bk.d_tile_p0 : e->d_tile_p0;
+        flags.ntiles = e->ntiles;
+        if (e->bk.K) {
+            flags.plastic0 = e->bk.d_plastic[0];
+            flags.plastic1 = e->bk.d_plastic[1];
+            flags.tile_b0 = e->bk.d_tile_b0;
+        }
+    }
+    if (e->d_grid_ctl) { // ghosts jumped: rebin (both parities: whichever the next maintain launch reads)
+        flags.force0 = &e->d_grid_ctl[0].force;
+        flags.force1 = &e->d_grid_ctl[1].force;
+    }
     k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->d_ghost_p_off,
                                                                 e->n_ghost_p, e->d_ghost_b, e->d_ghost_b_off,
-                                                                e->n_ghost_b_copies, src, e->d_broken, e->d_dead_gen);
-    if (e->d_grid_ctl) { // ghosts jumped: rebin (both parities: whichever the next maintain launch reads)
-        (void)hipMemsetAsync(&e->d_grid_ctl[0].force, 0x01, 4, e->stream);
-        (void)hipMemsetAsync(&e->d_grid_ctl[1].force, 0x01, 4, e->stream);
-    }
-    // ghost accelerations were overwritten: drop the "all zero" promise for this buffer
-    if (e->ntiles) (void)hipMemsetAsync(e->d_acc_flag[e->cur], 0x01, (size_t)e->ntiles * 4, e->stream);
-    // ... and so may ghost beams' targets have been (their owners' beams may have yielded): every tile reads and writes them from now on
-    if (e->bk.K && e->ntiles)
-        for (int b = 0; b < 2; b++) (void)hipMemsetAsync(e->bk.d_plastic[b], 0x01, (size_t)e->ntiles * 4, e->stream);
+                                                                e->n_ghost_b_copies, src, e->d_broken, e->d_dead_gen, flags);
 }
 
 static inline size_t sb_mailbox_stride(uint32_t recv_floats)

@@ -47,8 +47,8 @@ def test_default_line_carries_the_contract():
 
 
 def test_two_ranks_with_the_drivers_arguments():
-    """`--steps 20 --warmup 5` is what the driver runs: the timed region must hold a ghost refresh (at the default depth of
-    30 it used to hold none), and the N > 1 line carries `roofline` and `cpu_baseline` like the N = 1 line."""
+    """`--steps 20 --warmup 5` is what the driver runs: the timed region must hold a ghost refresh (at a fixed depth of 30 it
+    used to hold none), and the N > 1 line carries `roofline` and `cpu_baseline` like the N = 1 line."""
     d = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", timeout=1200)
     assert d["n_gpus"] == 2 and d["value"] > 1.0e10 and "REHEARSAL" in d["data"]
     x = d["config"]["exchange"]
@@ -66,4 +66,4 @@ def test_two_ranks_with_the_drivers_arguments():
 def test_two_ranks_long_region_keeps_the_depth_asked_for():
     d = run_bench("--gpus", "2", "--rehearse-one-gpu", "--steps", "120", "--warmup", "30", "--no-extra", "--no-cpu-baseline")
     assert d["n_gpus"] == 2 and d["value"] > 1.0e10 and "REHEARSAL" in d["data"]
-    assert d["config"]["exchange"]["ghost_depth"] == 30 and d["config"]["exchange"]["exchanges_in_timed_region"] == 4
+    assert d["config"]["exchange"]["ghost_depth"] == 24 and d["config"]["exchange"]["exchanges_in_timed_region"] == 5

@@ -22,7 +22,7 @@ eng.step(64)
 BASE_US = eng.step_timed(500) * 1e3 / 500   # the same slab without ghost columns, us per substep
 eng.destroy()
 del base
-for depth in (12, 18, 30, 36):
+for depth in (12, 18, 24, 30):
     for transport in ("rccl", "peer"):
         buf, plan = sb.halo.slab_scene(sb, 1, 3, W, H, jitter=1.0, depth=depth)
         eng = sb.Engine(bounds_size=100000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=0)
