@@ -118,8 +118,26 @@ static void reap_join(sb_engine *e)
     if (e->reaper.joinable()) e->reaper.join();
 }
 
+// The blocked plan of an SB_COLLIDE_GRID engine (e->hy) costs what a blocked plan costs -- 65 ms of host time per million
+// particles -- and only a scene that is ever quiet uses it.  The upload therefore only STARTS it, on a side thread, from copies of
+// the positions and the engine's own beam records (which stay put until the next upload that plans, and that one joins first).
+struct SbHybridPending {
+    std::thread th;
+    SbBlocking bl;
+    std::vector<float> px, py;
+    uint32_t target = 0, depth = 0;
+};
+static void hybrid_pending_drop(sb_engine *e)
+{
+    if (!e->hy_pending) return;
+    if (e->hy_pending->th.joinable()) e->hy_pending->th.join();
+    delete e->hy_pending;
+    e->hy_pending = nullptr;
+}
+
 static void free_scene(sb_engine *e)
 {
+    hybrid_pending_drop(e);
     for (void *p : e->allocs) (void)hipFree(p); // (what does not go through the pool: the fine-grained mailbox)
     e->allocs.clear();
     e->pool_free.insert(e->pool_free.end(), e->pool_used.begin(), e->pool_used.end());
@@ -754,8 +772,8 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
         if (h.synced_delete_gen && h.entries)
             SB_HIP(e, hipMemcpyAsync(h.d_ent_word, h.d_ent_word0, (size_t)h.entries * 4, hipMemcpyDeviceToDevice, e->stream));
         h.synced_delete_gen = 0;
-        h.slow_chunk = h.slow_left = 0;
     }
+    e->hy.slow_chunk = e->hy.slow_left = 0; // (also while its plan is still on the side thread: that one only depends on the topology)
     tm.mark("beam state to device");
     if (e->d_acc_flag[0]) { // buffer A holds whatever accelerations were uploaded; buffer B is all zeros (engineWorker.ts:593)
         SB_HIP(e, hipMemsetAsync(e->d_acc_flag[0], 0x01, std::max<size_t>(e->ntiles, 1) * 4, e->stream));
@@ -1237,31 +1255,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     // reference always runs, is then a no-op and K substeps can go out of LDS and registers as with collisions off).
     // hybrid_substeps below decides substep run by substep run; every other entry point only ever sees the tiled layout.
     e->hy = SbBlockedDev{};
-    {
-        static const bool hybrid_off = [] { const char *v = getenv("SB_HYBRID"); return v && atoi(v) == 0; }();
-        if (!hybrid_off && e->path == SB_PATH_TILED && e->opt.collision_mode == SB_COLLIDE_GRID && e->opt.block_substeps != 1 && P && B &&
-            tl.ntiles) {
-            uint32_t hk = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
-            SbBlocking hbl;
-            sb_build_blocking(hbl, px, py, hb, tile_target_used, hk);
-            auto fits = [&](uint32_t d) {
-                return hbl.max_own <= SB_BK_OWNP * SB_BK_T && hbl.halo_at[d] <= SB_BK_HALOP * SB_BK_T && hbl.max_ownb <= SB_BK_OWNB * SB_BK_T &&
-                       hbl.halo_entries_at[d] <= SB_BK_HALOB * SB_BK_T && hbl.region_at[d] <= (1u << SB_BK_LBITS) - 2u;
-            };
-            if (!fits(hk)) {
-                uint32_t fit = 0;
-                for (uint32_t d = 2; d < hk; d++)
-                    if (fits(d)) fit = d;
-                hk = fit;
-            }
-            // the two plans must agree on the particle order and on the tiles (same bisection of the same positions)
-            if (hk && hbl.order == tl.order && hbl.tile_p0 == tl.tile_p0) {
-                SB_TRY(upload_blocked(e, hbl, hb, hk, tm, true, &e->h_copy_of_slot, &c_slot));
-                if (!hk) e->hy = SbBlockedDev{};
-            }
-            tm.mark("blocked plan beside the tiling");
-        }
-    }
+    e->h_tile_p0.assign(tl.tile_p0.begin(), tl.tile_p0.end());
     SB_TRY(dev_alloc(e, &e->d_dead_gen, B));
     SB_HIP(e, hipMemset(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4));
     e->delete_gen = 0;
@@ -1271,6 +1265,20 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     e->loaded = true;
     pool_trim(e);
     tm.mark("masks + final sync");
+    {
+        static const bool hybrid_off = [] { const char *v = getenv("SB_HYBRID"); return v && atoi(v) == 0; }();
+        if (!hybrid_off && e->path == SB_PATH_TILED && e->opt.collision_mode == SB_COLLIDE_GRID && e->opt.block_substeps != 1 && P && B &&
+            tl.ntiles) {
+            auto *p = new SbHybridPending;
+            p->px = px;
+            p->py = py;
+            p->target = tile_target_used;
+            p->depth = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
+            const SbHostBeams *beams = &e->h_beams;
+            p->th = std::thread([p, beams] { sb_build_blocking(p->bl, p->px, p->py, *beams, p->target, p->depth); });
+            e->hy_pending = p;
+        }
+    }
     {
         auto *trash = new SbUploadTrash;
         trash->px.swap(px);
@@ -1328,6 +1336,37 @@ sb_status sb_get_physics_constants(sb_engine *e, float c8[8])
 //          read are intact (everything is double-buffered) -- and its substeps are redone one by one, where the hash gets rebuilt.
 // Every other entry point sees the tiled layout only.  Bit-exact by construction: a launch counts only if no contact could
 // have happened during it.
+// the side thread's plan goes to the device (first quiet look); afterwards e->hy.K says whether the scene can use it
+static sb_status hybrid_materialise(sb_engine *e)
+{
+    SbHybridPending *p = e->hy_pending;
+    if (!p) return SB_OK;
+    if (p->th.joinable()) p->th.join();
+    const SbBlocking &hbl = p->bl;
+    uint32_t hk = p->depth;
+    auto fits = [&](uint32_t d) {
+        return hbl.max_own <= SB_BK_OWNP * SB_BK_T && hbl.halo_at[d] <= SB_BK_HALOP * SB_BK_T && hbl.max_ownb <= SB_BK_OWNB * SB_BK_T &&
+               hbl.halo_entries_at[d] <= SB_BK_HALOB * SB_BK_T && hbl.region_at[d] <= (1u << SB_BK_LBITS) - 2u;
+    };
+    if (!fits(hk)) { // (launches of k substeps load the depth-k prefix of the plan: they just stay shallower)
+        uint32_t fit = 0;
+        for (uint32_t d = 2; d < hk; d++)
+            if (fits(d)) fit = d;
+        hk = fit;
+    }
+    sb_status st = SB_OK;
+    // the two plans must agree on the particle order and on the tiles (same bisection of the same positions)
+    if (hk && hbl.order == e->h_pslot && hbl.tile_p0 == e->h_tile_p0) {
+        SbStageTimer tm;
+        st = upload_blocked(e, hbl, e->h_beams, hk, tm, true, &e->h_copy_of_slot, &e->h_slot_of_copy);
+        if (st == SB_OK && !hk) e->hy = SbBlockedDev{};
+        tm.mark("blocked plan beside the tiling");
+    }
+    delete p;
+    e->hy_pending = nullptr;
+    return st;
+}
+
 static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
 {
     SbBlockedDev &h = e->hy;
@@ -1366,6 +1405,13 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
             continue;
         }
         h.slow_chunk = 0;
+        if (!h.K) { // quiet for the first time: now the plan is worth having on the device
+            SB_TRY(hybrid_materialise(e));
+            if (!h.K) { // (the scene cannot use one after all: more material rows than an entry word holds, a negative yield ...)
+                for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
+                return SB_OK;
+            }
+        }
         // ---- a run of tracked launches
         const uint32_t chunk = std::min<uint32_t>(n, 48u * h.K);
         uint32_t ks[64], count = 0, k_hi = 0, n_hi = 0;
@@ -1427,7 +1473,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
 static sb_status launch_substeps(sb_engine *e, uint32_t n)
 {
     if (e->bk.K) sbk_launch_blocked(e, n, true);
-    else if (e->hy.K) return hybrid_substeps(e, n);
+    else if (e->hy.K || e->hy_pending) return hybrid_substeps(e, n);
     else
         for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
     return SB_OK;
@@ -1750,7 +1796,8 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
         SB_HIP(e, hipStreamSynchronize(e->stream));
         *value = (i >= 0 && i < 7 && e->dev_err) ? e->dev_err[4 + i] : 0;
     }
-    else if (k == "hybrid") *value = e->hy.K;                         // depth of the blocked plan beside the tiling (0: none)
+    else if (k == "hybrid") *value = e->hy.K;                         // depth of the blocked plan beside the tiling (0: none, or not on the device yet)
+    else if (k == "hybrid_pending") *value = e->hy_pending ? 1 : 0;   // that plan is (being) made on the side thread and has not been needed yet
     else if (k == "hybrid_substeps") *value = e->hy.substeps_blocked; // substeps that ran blocked under SB_COLLIDE_GRID
     else if (k == "hybrid_failed") *value = e->hy.launches_failed;    // tracked launches that went over the skin and were redone
     else if (k == "material_mode") *value = e->mat_mode;

@@ -166,6 +166,9 @@ struct sb_engine {
     uint32_t *d_acc_flag[2] = {nullptr, nullptr}; // per particle buffer, per tile: 0 = every acc is zero
     SbBlockedDev bk;
     SbBlockedDev hy;                  // SB_COLLIDE_GRID: a blocked plan BESIDE the tiled layout, for the stretches in which nothing is within reach (hy.K != 0: available)
+    struct SbHybridPending *hy_pending = nullptr; // ... being made on a side thread since the upload; it goes to the device the first
+                                      // time the scene is found quiet (sb_api.hip hybrid_substeps), so a pile never pays for it
+    std::vector<uint32_t> h_tile_p0;  // the tiled layout's tiles (host copy: the two plans must agree on them)
     // beam word packing and material dictionary (tiled path)
     uint32_t lbits = 16;      // bits per tile-local endpoint index
     uint32_t mat_mode = 0;    // 0: per-copy parameter arrays; 1: table of (spring,damp,yield,limit) + per-copy length;
