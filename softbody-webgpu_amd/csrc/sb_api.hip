@@ -788,7 +788,6 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
         for (int k = 0; k < 2; k++) SB_HIP(e, hipMemsetAsync(e->d_blk_max[k], 0, e->grid_slots * 4, e->stream));
         SB_HIP(e, hipMemsetAsync(e->d_grid_done, 0, 4, e->stream));
         SB_HIP(e, hipMemsetAsync(e->d_grid_outside, 0, 8, e->stream));
-        SB_HIP(e, hipMemsetAsync(e->d_grid_nonempty, 0xFF, 4, e->stream));
         SB_HIP(e, hipMemsetAsync(e->d_nl_count, 0, std::max<size_t>(P, 1) * 4, e->stream));
         SB_HIP(e, hipMemcpyAsync(e->d_grid_ctl, e->grid_ctl0, sizeof e->grid_ctl0, hipMemcpyHostToDevice, e->stream));
         e->grid_par = 0;
@@ -1207,8 +1206,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_HIP(e, hipMemset(e->d_grid_done, 0, 4));
         SB_TRY(dev_alloc(e, &e->d_grid_outside, 2));
         SB_HIP(e, hipMemset(e->d_grid_outside, 0, 8));
-        SB_TRY(dev_alloc(e, &e->d_grid_nonempty, 1));
-        SB_HIP(e, hipMemset(e->d_grid_nonempty, 0xFF, 4)); // (no lists yet: not "all empty")
+        SB_TRY(dev_alloc(e, &e->d_grid_nonempty, 1 + 1024)); // (the hybrid look's answer and the per-workgroup minima behind it)
         SbGridCtl ctl[2] = {};
         for (int k = 0; k < 2; k++) {
             ctl[k].force = 1;
@@ -1380,10 +1378,10 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
             continue;
         }
         // ---- look
-        struct Look { SbGridCtl ctl; uint32_t nonempty; } *look = (Look *)(e->dev_err + 16); // (pinned; words 0..15 are the error and stamp words)
+        struct Look { SbGridCtl ctl; float min_d2; } *look = (Look *)(e->dev_err + 16); // (pinned; words 0..15 are the error and stamp words)
         SB_HIP(e, hipMemcpyAsync(&look->ctl, e->d_grid_ctl + e->grid_par, sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
-        sbk_launch_lists_nonempty(e); // (asked only here: a store from the list makers themselves cost the pile 5 us per substep)
-        SB_HIP(e, hipMemcpyAsync(&look->nonempty, e->d_grid_nonempty, 4, hipMemcpyDeviceToHost, e->stream));
+        sbk_launch_lists_min_d2(e); // (asked only here, by kernels of its own)
+        SB_HIP(e, hipMemcpyAsync(&look->min_d2, e->d_grid_nonempty, 4, hipMemcpyDeviceToHost, e->stream));
         SB_HIP(e, hipStreamSynchronize(e->stream));
         const SbGridCtl ctl = look->ctl;
         auto force_rebuild = [&]() -> sb_status { // the next maintenance launch rebuilds the hash, the substep after it makes the lists
@@ -1395,13 +1393,38 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
             h.slow_left = std::min<uint32_t>(n, 2u);
             continue;
         }
-        if (look->nonempty != 0u || e->n_ghost_p != 0 || e->n_send_p != 0) { // somebody within reach (or ghost zones: not handled here)
+        // Nobody within 2r + 2 skin of anybody (every list empty): no contact while the hash's bound stays inside its skin.
+        // Somebody listed, the closest such pair d apart: two particles approach each other by at most twice the displacement
+        // bound (it is measured against a common drift), so no LISTED pair touches either while the bound grows by less than
+        // gap = (d - 2r) / 2 from here -- the run's budget is the smaller of the two.  A pair AT 2r or closer: not quiet.
+        float gap = INFINITY;
+        if (look->min_d2 < INFINITY) gap = 0.5f * ((float)(std::sqrt((double)look->min_d2) * (1.0 - 1.0e-6)) - e->grid.two_r);
+        if (!(gap > 0.0f)) gap = 0.0f; // (NaN, or in contact)
+        const float budget = std::min(ctl.skin - ctl.accum, gap);
+        static const bool debug = getenv("SB_HYBRID_DEBUG") != nullptr;
+        if (debug)
+            fprintf(stderr, "[sb hybrid] look: n %u builds %u accum %g skin %g since %u closest listed pair %g gap %g budget %g K %u pending %d\n", n,
+                    ctl.builds, ctl.accum, ctl.skin, ctl.since, std::sqrt((double)look->min_d2), gap, budget, h.K, e->hy_pending ? 1 : 0);
+        if (e->n_ghost_p != 0 || e->n_send_p != 0 || !(gap >= 0.15f * ctl.skin)) { // somebody (nearly) touching, or ghost zones (not handled here)
             h.slow_chunk = std::min<uint32_t>(std::max<uint32_t>(16u, 2u * h.slow_chunk), 1024u);
             h.slow_left = std::min(n, h.slow_chunk);
             continue;
         }
-        if (!(ctl.accum <= 0.7f * ctl.skin)) { // quiet, but little of the skin left: a fresh hash is cheaper than a run that fails
+        if (!(budget >= 0.15f * ctl.skin)) { // quiet, but little of the skin left: a fresh hash is cheaper than a run that fails
             SB_TRY(force_rebuild());
+            continue;
+        }
+        // How long will the budget last?  The last tracked run measured how fast the bound grows (h.rate, per substep; the
+        // hash's own accum / since is no guide right after a build, while its drift estimate is still settling).  A run costs a
+        // dozen launches' worth of fixed work (two conversions, two syncs, the rebuild that follows), so one that the budget
+        // would end within 32 substeps is not started -- two blobs flying at each other use the skin up in ten -- and a longer
+        // one is cut to 0.8 of the prediction, so that it ends with its last launch validated rather than with one refused.
+        // An old measurement fades (halved at every look that turns a run down), so a scene that calms down is tried again.
+        const float lasts = h.rate > 0.0f ? budget / h.rate : 1.0e9f;
+        if (!(lasts >= 32.0f)) {
+            h.rate *= 0.5f;
+            h.slow_chunk = std::min<uint32_t>(std::max<uint32_t>(16u, 2u * h.slow_chunk), 1024u);
+            h.slow_left = std::min(n, h.slow_chunk);
             continue;
         }
         h.slow_chunk = 0;
@@ -1413,7 +1436,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
             }
         }
         // ---- a run of tracked launches
-        const uint32_t chunk = std::min<uint32_t>(n, 48u * h.K);
+        const uint32_t chunk = std::min<uint32_t>(std::min<uint32_t>(n, 48u * h.K), (uint32_t)std::min(0.8f * lasts, 1.0e6f));
         uint32_t ks[64], count = 0, k_hi = 0, n_hi = 0;
         const uint32_t L = sbk_split_call(chunk, h.K, false, &k_hi, &n_hi);
         for (uint32_t i = 0; i < L && count < 64u; i++) ks[count++] = i < n_hi ? k_hi : k_hi - 1u;
@@ -1426,7 +1449,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         q.Cy = ctl.Cy;
         q.cx = ctl.cx;
         q.cy = ctl.cy;
-        q.skin = ctl.skin;
+        q.skin = std::min(ctl.skin, ctl.accum + gap); // (the validation's limit for the bound: the skin, or the gap of the closest listed pair)
         q.fail_at = 0xFFFFFFFFu;
         if (fail_every && (h.launches_ok + h.launches_failed + count) / fail_every != (h.launches_ok + h.launches_failed) / fail_every)
             q.fail_at = fail_every - 1u - (uint32_t)((h.launches_ok + h.launches_failed) % fail_every); // (tests: a roll-back every so many launches)
@@ -1448,6 +1471,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         sbk_hybrid_to_tiled(e, done == count && aux_last);
         h.launches_ok += done;
         h.substeps_blocked += q.substeps;
+        if (q.substeps) h.rate = std::max(q.D - ctl.accum, 0.0f) / (float)q.substeps;
         // the hash's bookkeeping, as if its maintenance launch had run on every one of those substeps; the displacement
         // slots that launch reads next are from before the run (any drift estimate keeps the bound valid: zero)
         SbGridCtl upd = ctl;
@@ -1462,9 +1486,14 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         SB_HIP(e, hipMemsetAsync(e->d_blk_max[e->grid_par], 0, 3 * (size_t)(std::max<size_t>(e->ntiles, ((size_t)e->P + 255) / 256) + 1) * 4, e->stream));
         SB_HIP(e, hipStreamSynchronize(e->stream)); // (`look` is reused by the next look)
         n -= q.substeps;
-        if (done < count) { // over the budget (or told to fail, by a test): a fresh hash, then look again
-            h.launches_failed += 1;
+        if (done < count) { // over the budget (or told to fail, by a test): a fresh hash, then look again -- after a stretch of
+            h.launches_failed += 1; // single substeps that doubles with every refusal in a row (a scene that keeps using its budget up
+            if (done >= 2u) h.fail_streak = 0;          // (a run that got somewhere and then met its budget: the ordinary end of a run)
+            else if (done != q.fail_at) h.fail_streak++; // within a launch or two is cheaper substep by substep; a test's refusals do not count)
             SB_TRY(force_rebuild());
+            if (h.fail_streak > 1u) h.slow_left = std::min<uint32_t>(n, 8u << std::min<uint32_t>(h.fail_streak, 7u));
+        } else {
+            h.fail_streak = 0;
         }
     }
     return SB_OK;

@@ -562,17 +562,29 @@ __global__ __launch_bounds__(1024) void k_hybrid_validate(const uint32_t *__rest
 // beam state between the two device layouts of an SB_COLLIDE_GRID engine that can run blocked (sb_api.hip hybrid_step): the
 // tiled layout (one copy per tile that holds an endpoint) is where the state lives between API calls; the blocked layout
 // (one slot per beam) borrows it for a run of blocked launches
+// One workgroup per tile of the blocked plan: its own beams are entries e0 .. of the tile, in the order of the state slots
+// b0 .. (k_substep_blocked), so the rest length of each is at hand -- and with it the tile's plastic flag as of NOW: 0 = every
+// own beam's target is its rest length, bit for bit (what the tile's launches then neither read nor write).
 __global__ __launch_bounds__(256) void k_hybrid_to_blocked(const float *__restrict__ t_target, const float *__restrict__ t_last,
-                                                           const uint32_t *__restrict__ copy_of_g, uint32_t nb, float *b_target,
-                                                           float *b_target_other, float *b_last)
+                                                           const uint32_t *__restrict__ copy_of_g, const uint32_t *__restrict__ tile_b0,
+                                                           const uint32_t *__restrict__ tile_e0, const uint32_t *__restrict__ ent_word,
+                                                           const float *__restrict__ ent_length, const float *__restrict__ mat_tab,
+                                                           float *b_target, float *b_target_other, float *b_last, uint32_t *plastic_a,
+                                                           uint32_t *plastic_b)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= nb) return;
-    const uint32_t cpy = copy_of_g[g];
-    const float t = t_target[cpy];
-    b_target[g] = t;
-    b_target_other[g] = t; // (a tile that does not yield never stores its targets: both buffers must hold them)
-    b_last[g] = t_last[cpy];
+    const uint32_t tile = blockIdx.x, b0 = tile_b0[tile], nb = tile_b0[tile + 1] - b0, e0 = tile_e0[tile];
+    bool differs = false;
+    for (uint32_t j = threadIdx.x; j < nb; j += 256u) {
+        const uint32_t g = b0 + j, cpy = copy_of_g[g];
+        const float t = t_target[cpy];
+        const float rest = ent_length ? ent_length[e0 + j] : mat_tab[6u * (ent_word[e0 + j] >> (2u * SB_BK_LBITS))];
+        differs |= __float_as_uint(t) != __float_as_uint(rest);
+        b_target[g] = t;
+        b_target_other[g] = t; // (a tile that does not yield never stores its targets: both buffers must hold them)
+        b_last[g] = t_last[cpy];
+    }
+    const int any = __syncthreads_or(differs ? 1 : 0);
+    if (threadIdx.x == 0u) plastic_a[tile] = plastic_b[tile] = any ? 1u : 0u;
 }
 __global__ __launch_bounds__(256) void k_hybrid_to_tiled(const float *__restrict__ b_target, const float *__restrict__ b_last,
                                                          const float *__restrict__ b_strain, const float *__restrict__ b_stress,
@@ -732,13 +744,11 @@ void sbk_hybrid_to_blocked(sb_engine *e)
                                                                         h.d_ent_word, h.dummy_word);
         h.synced_delete_gen = e->delete_gen;
     }
-    k_hybrid_to_blocked<<<cdiv_b(B, 256), 256, 0, e->stream>>>(e->beams.target, e->beams.last, h.d_copy_of_g, B, h.d_target[h.cur],
-                                                               h.d_target[h.cur ^ 1u], h.d_last[h.cur]);
+    k_hybrid_to_blocked<<<h.ntiles, 256, 0, e->stream>>>(e->beams.target, e->beams.last, h.d_copy_of_g, h.d_tile_b0, h.d_tile_e0, h.d_ent_word,
+                                                         h.mat_mode == 1 ? h.d_ent_length : nullptr, h.d_mat, h.d_target[h.cur],
+                                                         h.d_target[h.cur ^ 1u], h.d_last[h.cur], h.d_plastic[0], h.d_plastic[1]);
     (void)hipMemsetAsync(h.d_broken, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
     (void)hipMemsetAsync(h.d_broken_new, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
-    // (the plastic flags stay as they are: they only ever go up, and a target that moved while the state lived in the tiled
-    // layout moved on BOTH of that layout's copies of a cut beam -- set them all, the simple and safe reading)
-    for (int b = 0; b < 2; b++) (void)hipMemsetAsync(h.d_plastic[b], 0x01, (size_t)std::max(h.ntiles, 1u) * 4, e->stream);
 }
 void sbk_hybrid_to_tiled(sb_engine *e, bool aux)
 {

@@ -88,6 +88,8 @@ struct SbBlockedDev {
     SbHybridCtl *d_q = nullptr;
     uint32_t *d_dmax = nullptr;       // per tile: largest displacement sum of the last tracked launch (float bits)
     uint32_t synced_delete_gen = 0;   // delete passes of the tiled layout this plan has seen
+    float rate = 0.0f;                // growth of the displacement bound per substep, as the last tracked run measured it (0: not known)
+    uint32_t fail_streak = 0;         // tracked runs refused in a row (each doubles the stretch of single substeps before the next look)
     uint32_t slow_chunk = 0, slow_left = 0; // substeps to run substep by substep before looking again whether the scene is quiet (doubles while it is not)
     uint64_t launches_ok = 0, launches_failed = 0, substeps_blocked = 0;
     uint32_t k_long = 0;      // substeps per launch of a long call (what the traffic model prices)
@@ -185,7 +187,7 @@ struct sb_engine {
     SbGridCtl *d_grid_ctl = nullptr;  // [2] rebuild decision state by substep parity (device resident: no host sync per substep)
     uint32_t *d_blk_max[2] = {};      // per workgroup of the particle kernel: largest displacement (float bits), by parity
     uint32_t *d_nl_count = nullptr, *d_nl = nullptr; // neighbour lists (SbGrid)
-    uint32_t *d_grid_nonempty = nullptr; // sbk_launch_lists_nonempty: 0 = every neighbour list of the hash in force is empty
+    uint32_t *d_grid_nonempty = nullptr; // sbk_launch_lists_min_d2: [0] = squared distance of the closest listed pair (+inf: every list empty), [1 ..] per-workgroup minima
     uint32_t *d_grid_outside = nullptr; // particles the hash build in progress found outside its frame (zero between builds)
     uint32_t *d_grid_done = nullptr;  // workgroups of the hash build in progress that have finished (zero between builds)
     uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
@@ -208,7 +210,7 @@ struct sb_engine {
 // sb_kernels.hip
 void sbk_launch_substep(sb_engine *e, bool write_aux);
 void sbk_launch_delete(sb_engine *e);
-void sbk_launch_lists_nonempty(sb_engine *e); // e->d_grid_nonempty = any neighbour list not empty (hybrid look)
+void sbk_launch_lists_min_d2(sb_engine *e); // e->d_grid_nonempty[0] = squared distance of the closest pair any neighbour list holds (float; hybrid look)
 void sbk_launch_halo_clear_ghost_flags(sb_engine *e);
 void sbk_launch_halo_pack(sb_engine *e, float *dst);
 void sbk_launch_halo_unpack(sb_engine *e, const float *src);

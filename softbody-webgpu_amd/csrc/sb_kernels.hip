@@ -842,20 +842,53 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
     e->substeps_done++;
 }
 
-// Is anybody on anybody's neighbour list?  Asked by the host between launches (sb_api.hip hybrid_substeps), never on the
-// substep path: the word is cleared, then set by the first wave that finds a count that is not zero (SB_NL_OVERFLOW counts).
-__global__ __launch_bounds__(SB_BLOCK) void k_lists_nonempty(const uint32_t *__restrict__ nl_count, uint32_t P, uint32_t *out)
+// How close is the closest pair any neighbour list holds?  Asked by the host between launches (sb_api.hip hybrid_substeps),
+// never on the substep path.  Squared distance (float bits; +inf = every list is empty, 0 = a list overflowed or holds a NaN),
+// per workgroup into `blk`, then one small launch takes the minimum -- NOT one atomic per wave on a shared word: same-address
+// traffic from the whole device costs ~30 ns per access here (a flag stored by the list makers themselves cost the pile 60 us
+// per substep).
+__global__ __launch_bounds__(SB_BLOCK) void k_lists_min_d2(const uint32_t *__restrict__ nl_count, const uint32_t *__restrict__ nl,
+                                                           uint32_t stride, const float2 *__restrict__ pos, uint32_t P, float *blk)
 {
-    bool any = false;
-    for (uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x; i < P; i += gridDim.x * SB_BLOCK) any |= nl_count[i] != 0u;
-    if (__builtin_amdgcn_ballot_w64(any) != 0ull && (threadIdx.x & 63u) == 0u && SB_AGENT_LOAD(out) == 0u) SB_AGENT_STORE(out, 1u);
+    __shared__ float s_min[SB_BLOCK / 64];
+    float best = INFINITY;
+    for (uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x; i < P; i += gridDim.x * SB_BLOCK) {
+        const uint32_t n = nl_count[i];
+        if (n == SB_NL_OVERFLOW) best = 0.0f;
+        else if (n) {
+            const float2 p = pos[i];
+            for (uint32_t k = 0; k < n; k++) {
+                const float2 q = pos[nl[(size_t)k * stride + i]];
+                const float dx = q.x - p.x, dy = q.y - p.y, d2 = dx * dx + dy * dy;
+                best = d2 == d2 ? fminf(best, d2) : 0.0f;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63u) == 0u) s_min[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        for (uint32_t w = 1; w < SB_BLOCK / 64; w++) best = fminf(best, s_min[w]);
+        blk[blockIdx.x] = best;
+    }
+}
+__global__ __launch_bounds__(256) void k_min_of(const float *__restrict__ blk, uint32_t n, float *out)
+{
+    __shared__ float s_min[4];
+    float best = INFINITY;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) best = fminf(best, blk[i]);
+    for (int o = 32; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63u) == 0u) s_min[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0u) *out = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
 }
 
-void sbk_launch_lists_nonempty(sb_engine *e)
+void sbk_launch_lists_min_d2(sb_engine *e)
 {
-    (void)hipMemsetAsync(e->d_grid_nonempty, 0, 4, e->stream);
-    k_lists_nonempty<<<std::min(std::max(cdiv(e->P, SB_BLOCK * 4u), 1u), 2048u), SB_BLOCK, 0, e->stream>>>(e->grid.nl_count, e->P,
-                                                                                                            e->d_grid_nonempty);
+    const uint32_t blocks = std::min(std::max(cdiv(e->P, SB_BLOCK * 4u), 1u), 1024u);
+    k_lists_min_d2<<<blocks, SB_BLOCK, 0, e->stream>>>(e->grid.nl_count, e->grid.nl, e->grid.nl_stride, e->part[e->cur].pos, e->P,
+                                                      (float *)e->d_grid_nonempty + 1);
+    k_min_of<<<1, 256, 0, e->stream>>>((const float *)e->d_grid_nonempty + 1, blocks, (float *)e->d_grid_nonempty);
 }
 
 void sbk_launch_delete(sb_engine *e)

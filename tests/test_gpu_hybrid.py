@@ -57,10 +57,12 @@ def test_frames_with_yield_break_and_delete_passes(sb, oracle):
 
 
 def test_two_blobs_meet(sb, oracle):
-    """Two lattice blobs on a collision course: quiet (blocked) while apart, substep by substep with lists once they are
-    within reach, bit-exact through the transition."""
-    a = sb.scenes.lattice_buffers(24, 24, d=30.0, origin=(200.0, 400.0), jitter=0.5, layout=2, velocity=(18.0, 0.0))
-    b = sb.scenes.lattice_buffers(24, 24, d=30.0, origin=(1100.0, 415.0), jitter=0.5, layout=2, velocity=(-18.0, 0.0), seed=7)
+    """Two lattice blobs on a collision course: quiet (blocked, in runs as long as the hash's skin lasts) while apart, blocked
+    against the shrinking gap of the closest listed pair once they are within reach of each other, substep by substep when they
+    touch -- bit-exact through the transitions.  (At four times the speed the skin lasts ten substeps and runs are not worth
+    starting: test_fast_blobs_stay_on_single_substeps.)"""
+    a = sb.scenes.lattice_buffers(24, 24, d=30.0, origin=(200.0, 400.0), jitter=0.5, layout=2, velocity=(4.0, 0.0))
+    b = sb.scenes.lattice_buffers(24, 24, d=30.0, origin=(950.0, 415.0), jitter=0.5, layout=2, velocity=(-4.0, 0.0), seed=7)
     P, B = a.particle_count, a.beam_count
     pv = np.concatenate([a.particles[:P], b.particles[:P]])
     beams = np.concatenate([a.beams[:B], b.beams[:B]])
@@ -73,6 +75,23 @@ def test_two_blobs_meet(sb, oracle):
     assert_same(got, exp, "two blobs meet")
     _, off, _ = run(sb, oracle, buf, bounds=3000.0, n=160, calls=6, ref_mode=OFF)
     assert (off.particles[:2 * P] != exp.particles[:2 * P]).any(), "the blobs must really collide"
+
+
+def test_fast_blobs_stay_on_single_substeps(sb, oracle):
+    """The same two blobs at +-18: the displacement bound uses the skin up every ten substeps, the first tracked run measures
+    that, and the engine goes back to single substeps (a run costs a dozen launches of fixed work) -- same bits either way."""
+    a = sb.scenes.lattice_buffers(24, 24, d=30.0, origin=(200.0, 400.0), jitter=0.5, layout=2, velocity=(18.0, 0.0))
+    b = sb.scenes.lattice_buffers(24, 24, d=30.0, origin=(1100.0, 415.0), jitter=0.5, layout=2, velocity=(-18.0, 0.0), seed=7)
+    P, B = a.particle_count, a.beam_count
+    pv = np.concatenate([a.particles[:P], b.particles[:P]])
+    beams = np.concatenate([a.beams[:B], b.beams[:B]])
+    beams["a"][B:] += P
+    beams["b"][B:] += P
+    buf = sb.Buffers(2, 2 * P, 2 * B)
+    buf.set_scene(pv, beams)
+    got, exp, info = run(sb, oracle, buf, bounds=3000.0, n=160, calls=6)
+    assert info["hybrid_substeps"] < 200, info
+    assert_same(got, exp, "fast blobs")
 
 
 FORCED = r"""
