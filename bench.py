@@ -385,6 +385,32 @@ def measure_steady_state(sb, a, buf, bounds, mode):
     return rec
 
 
+def measure_default_mode(sb, a, buf, bounds):
+    """The main scene once more with the engine's DEFAULT collision mode (spatial hash on -- the reference always collides,
+    compute.wgsl:142-170): nothing touches in config 2's lattice, so the engine runs blocked launches while the closest listed
+    pair stays clear of 2r.  Same step counts as `steady_state`.  Never `value`."""
+    eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=a.subticks, layout=2, max_particles=buf.max_particles,
+                    max_beams=buf.max_beams, collision_mode=2, block_substeps=a.block_substeps, grid_skin=a.grid_skin)
+    t0 = time.perf_counter()
+    eng.write_buffers(buf)
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    eng.step(64)
+    eng.sync()
+    done0, blocked0 = eng.info("substeps_done"), eng.info("hybrid_substeps")
+    t0 = time.perf_counter()
+    ms = eng.step_timed(a.steady_steps)
+    eng.sync()
+    wall = time.perf_counter() - t0
+    rec = {"steps": a.steady_steps, "warmup": 64, "value": buf.particle_count * a.steady_steps / wall, "unit": "particle-steps/s",
+           "us_per_substep": ms * 1e3 / a.steady_steps, "upload_ms": upload_ms,
+           "substeps_in_blocked_launches": eng.info("hybrid_substeps") - blocked0, "substeps": eng.info("substeps_done") - done0,
+           "launches_refused": eng.info("hybrid_failed"), "grid_builds": eng.info("grid_builds"),
+           "note": "collision_mode = SB_COLLIDE_GRID (sb_default_options); the timed region includes the looks, conversions, "
+                   "validations and the single substeps around every hash rebuild"}
+    eng.destroy()
+    return rec
+
+
 def measure_config3(sb, a):
     """BASELINE config 3 in the same run (rank 0, N=1): the blob pile, spatial-hash collisions, same step counts."""
     import numpy as np
@@ -669,6 +695,8 @@ def main():
                 if mode == 0 and line["roofline"] and line["roofline"]["substeps_per_launch"] > 1:
                     extra["single_substep_kernel"] = measure_single_substep(sb, a, buf, bounds, rec["workload"])
                 extra["steady_state"] = measure_steady_state(sb, a, buf, bounds, mode)
+                if plain and mode == 0:
+                    extra["default_collision_mode"] = measure_default_mode(sb, a, buf, bounds)
                 if plain:
                     extra["config3"] = measure_config3(sb, a)
             del buf

@@ -42,6 +42,9 @@ def test_default_line_carries_the_contract():
     # the steady-state figure DESIGN.md quotes rides in the same record (never `value`), and so do one GPU's shares of configs 4 and 5
     assert ex["steady_state"]["steps"] == 960 and ex["steady_state"]["value"] > 1.0e10
     assert ex["config3"]["steady_state"]["steps"] == 960
+    # ... and the same scene with the engine's default collision mode (hash on): mostly blocked launches, far above the hash-only rate
+    dm = ex["default_collision_mode"]
+    assert dm["substeps"] == 960 and dm["substeps_in_blocked_launches"] > 800 and dm["value"] > 5.0e10
     for k, particles in (("config4_share", 500 * 4000), ("config5_share", 1000 * 8000)):
         assert ex[k]["particles_total"] == particles and ex[k]["value"] > 1.0e10 and 0.0 < ex[k]["roofline"]["frac"] <= 1.0
 
