@@ -300,14 +300,22 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
     per_substep_s = kernel_ms * 1e-3 / steps
     own = float(eng.info("substep_hbm_bytes"))
     k = max(1, eng.info("substeps_per_launch"))
-    ach = own / per_substep_s / 1e9
     tiled = eng.info("path") == 2
+    hybrid_bytes = float(eng.info("hybrid_substep_hbm_bytes"))
+    if hybrid_bytes:
+        # SB_COLLIDE_GRID engine that ran blocked launches while nothing was about to touch: most substeps moved
+        # the blocked kernel's bytes, not the single-substep kernel's.  The shares are those of the engine's whole life since
+        # the upload (warm-up included); the launches are k_substep_blocked<..., TRACK> + k_hybrid_validate.
+        done, blocked = float(eng.info("substeps_done")), float(eng.info("hybrid_substeps"))
+        share = blocked / done if done else 0.0
+        own = share * hybrid_bytes + (1.0 - share) * own
+    ach = own / per_substep_s / 1e9
     roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": None,
             "kernel": eng.kernel_name() if tiled else "k_beams_atomic+k_particles",
             "substeps_per_launch": k, "avg_launch_us": per_substep_s * k * 1e6,
             "compulsory_bytes_per_launch": own * k,
-            "binding_roof": "valu_issue" if k > 1 else "hbm",
+            "binding_roof": "valu_issue" if (k > 1 or hybrid_bytes) else "hbm",
             "reference_layout_bytes_per_substep": 52.0 * B_local + 48.0 * P_local,
             "reference_layout_equiv_GBps": (52.0 * B_local + 48.0 * P_local) / per_substep_s / 1e9,
             "note": "achieved = compulsory bytes of the launched kernel (engine's own data layout: %d beam copies for %d "
@@ -317,6 +325,14 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
                     "streaming the reference's records would need to sustain for this step rate -- an equivalence, not a "
                     "fraction of the roof"
                     % (eng.info("beam_copies"), B_local, eng.info("material_mode"), k, eng.info("plan_depth"))}
+    if hybrid_bytes:
+        roof["kernel"] = "k_substep_blocked<TRACK> + k_hybrid_validate (%.0f %% of the substeps), %s (the rest)" % (100.0 * share, roof["kernel"])
+        roof["substeps_per_launch"] = eng.info("hybrid_substeps_per_launch")
+        roof["avg_launch_us"] = None
+        roof["compulsory_bytes_per_launch"] = None
+        roof["note"] = ("achieved = compulsory bytes per substep, weighted by the share of substeps that ran in blocked launches "
+                        "(%d per launch) and in single substeps, / HIP-event time per substep of the timed region" % roof["substeps_per_launch"])
+        return roof
     tr = committed_traffic(workload, roof["kernel"].split("<")[0])
     if tr:
         roof["traffic"] = tr[0]

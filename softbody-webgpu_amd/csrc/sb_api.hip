@@ -1736,21 +1736,25 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
 // of profiles/ must reproduce).  Counted: every array element the kernel reads or writes once per substep.
 // Not counted: accelerations (skipped while they are zero), strain/stress (stored by the last
 // substep of a call only), target stores (plastic yield only), neighbour-list traffic of SB_COLLIDE_GRID.
+// one launch of a long call of a blocked plan = k_long substeps: every entry word of that depth, the state of every halo entry
+// (index + target + last, gathered), the owned states in and out, own particles in and out, halo particles (index + position +
+// velocity); per substep
+static uint64_t blocked_bytes_model(const sb_engine *e, const SbBlockedDev &bk)
+{
+    const uint64_t P = e->P, nb = bk.nbeams;
+    const uint32_t k = bk.k_long;
+    const uint64_t entries = bk.entries_at[k], halo_entries = entries - std::min<uint64_t>(entries, nb),
+                   halo_particles = bk.region_at[k] - std::min<uint64_t>(bk.region_at[k], P);
+    // (targets: neither read, written nor gathered while no tile has yielded; priced as of the upload)
+    const uint64_t per_launch = entries * (4 + (bk.mat_mode == 1 ? 4 : 0)) + halo_entries * (bk.pristine ? 8 : 12) + nb * (bk.pristine ? 8 : 16) + P * 32 +
+                                halo_particles * 20 + (uint64_t)bk.ntiles * (8 * 4 + 8 * k) + (uint64_t)bk.nmat * 24;
+    return per_launch / k;
+}
+
 static uint64_t substep_bytes_model(const sb_engine *e)
 {
     const uint64_t P = e->P, nc = e->nbeam;
-    if (e->bk.K) {
-        // one launch of a long call = k_long substeps: every entry word of that depth, the state of every halo entry (index +
-        // target + last, gathered), the owned states in and out, own particles in and out, halo particles (index + position +
-        // velocity)
-        const uint32_t k = e->bk.k_long;
-        const uint64_t entries = e->bk.entries_at[k], halo_entries = entries - std::min<uint64_t>(entries, nc),
-                       halo_particles = e->bk.region_at[k] - std::min<uint64_t>(e->bk.region_at[k], P);
-        // (targets: neither read, written nor gathered while no tile has yielded; priced as of the upload)
-        const uint64_t per_launch = entries * (4 + (e->mat_mode == 1 ? 4 : 0)) + halo_entries * (e->bk.pristine ? 8 : 12) + nc * (e->bk.pristine ? 8 : 16) + P * 32 +
-                                    halo_particles * 20 + (uint64_t)e->ntiles * (8 * 4 + 8 * k) + (uint64_t)e->nmat * 24;
-        return per_launch / k;
-    }
+    if (e->bk.K) return blocked_bytes_model(e, e->bk);
     if (e->path == SB_PATH_TILED) {
         uint64_t per_copy = 4 /* endpoint word */ + 4 /* target */ + 4 + 4 /* last: read, written */;
         if (e->mat_mode <= 1) per_copy += 4;  // per-copy rest length
@@ -1826,6 +1830,8 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
         *value = (i >= 0 && i < 7 && e->dev_err) ? e->dev_err[4 + i] : 0;
     }
     else if (k == "hybrid") *value = e->hy.K;                         // depth of the blocked plan beside the tiling (0: none, or not on the device yet)
+    else if (k == "hybrid_substep_hbm_bytes") *value = e->hy.K ? blocked_bytes_model(e, e->hy) : 0; // of its blocked launches (k = hybrid_substeps_per_launch)
+    else if (k == "hybrid_substeps_per_launch") *value = e->hy.K ? e->hy.k_long : 0;
     else if (k == "hybrid_pending") *value = e->hy_pending ? 1 : 0;   // that plan is (being) made on the side thread and has not been needed yet
     else if (k == "hybrid_substeps") *value = e->hy.substeps_blocked; // substeps that ran blocked under SB_COLLIDE_GRID
     else if (k == "hybrid_failed") *value = e->hy.launches_failed;    // tracked launches that went over the skin and were redone
