@@ -1419,7 +1419,9 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         // dozen launches' worth of fixed work (two conversions, two syncs, the rebuild that follows), so one that the budget
         // would end within 32 substeps is not started -- two blobs flying at each other use the skin up in ten -- and a longer
         // one is cut to 0.8 of the prediction, so that it ends with its last launch validated rather than with one refused.
-        // An old measurement fades (halved at every look that turns a run down), so a scene that calms down is tried again.
+        // An old measurement fades (halved at every look that turns a run down), so a scene that calms down is tried again; a run
+        // that ends in a refusal after three validated launches has still paid for itself (a refusal costs about nine single
+        // substeps' time, a blocked substep saves half of one).
         const float lasts = h.rate > 0.0f ? budget / h.rate : 1.0e9f;
         if (!(lasts >= 32.0f)) {
             h.rate *= 0.5f;
@@ -1834,6 +1836,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "hybrid_substeps_per_launch") *value = e->hy.K ? e->hy.k_long : 0;
     else if (k == "hybrid_pending") *value = e->hy_pending ? 1 : 0;   // that plan is (being) made on the side thread and has not been needed yet
     else if (k == "hybrid_substeps") *value = e->hy.substeps_blocked; // substeps that ran blocked under SB_COLLIDE_GRID
+    else if (k == "hybrid_launches") *value = e->hy.launches_ok;      // tracked launches that were validated
     else if (k == "hybrid_failed") *value = e->hy.launches_failed;    // tracked launches that went over the skin and were redone
     else if (k == "material_mode") *value = e->mat_mode;
     else if (k == "materials") *value = e->nmat;

@@ -159,3 +159,91 @@ def test_random_beam_scene_blocked_equals_oracle(sb, oracle, seed):
         assert got.beams.tobytes() == exp.beams.tobytes(), "seed %d chunk %d beams" % (seed, k)
         assert np.array_equal(got.mapping, exp.mapping)
     eng.destroy()
+
+
+def make_quiet_case(sb, seed):
+    """Grid mode with room to be quiet in: lattice blobs dealt onto the squares of a coarse board (nobody overlaps anybody at
+    t = 0), drifting slowly, falling under gravity until they land on the floor, the walls or each other; yield and break
+    limits in reach; random tile size, block depth, constants and user input.  The engine's hybrid path goes
+    blocked while the closest listed pair stays clear, back to single substeps when somebody is about to touch."""
+    rng = np.random.default_rng(9000 + seed)
+    bounds = float(rng.choice([1600.0, 3000.0]))
+    square = 420.0
+    side = int((bounds - 40.0) // square)
+    squares = rng.permutation(side * side)[: int(rng.integers(2, min(9, side * side)))]
+    parts, beams, base = [], [], 0
+    for sq in squares:
+        d = float(rng.uniform(24.0, 34.0))
+        w, h = int(rng.integers(3, int(360.0 // d))), int(rng.integers(3, int(360.0 // d)))
+        ox, oy = 30.0 + (sq % side) * square + rng.uniform(0, 20), 30.0 + (sq // side) * square + rng.uniform(0, 20)
+        p, b = sb.scenes.rectangle(ox, oy, d, w, h, float(rng.choice([3, 50, 500])), float(rng.choice([50, 700])),
+                                   float(rng.choice([0.02, 0.2, 2.0])), float(rng.choice([0.1, 0.5, 1e9])), base=base,
+                                   anti_diagonal=bool(rng.integers(0, 2)), layout=2)
+        pv = np.zeros((p.shape[0], 6), "f4")
+        pv[:, :2] = p + rng.uniform(-0.8, 0.8, p.shape).astype("f4")
+        pv[:, 2:4] = rng.uniform(-6, 6, 2).astype("f4")
+        parts.append(pv)
+        beams.append(b)
+        base += p.shape[0]
+    P, B = np.concatenate(parts), np.concatenate(beams)
+    if rng.integers(0, 2):   # editor-style rest lengths: material mode 1, neighbours listed (28 .. 34 apart) but not touching
+        dx = P[B["b"], 0] - P[B["a"], 0]
+        dy = P[B["b"], 1] - P[B["a"], 1]
+        ln = np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+        for f in ("length", "target_length", "last_length"):
+            B[f] = ln
+    buf = sb.Buffers(2, P.shape[0] + 5, B.shape[0] + 3)
+    buf.set_scene(P, B)
+    consts = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.8, -0.1), rng.uniform(0, 1), rng.uniform(0, 1),
+                       rng.uniform(0, 1), rng.uniform(0, 1), 0.002, 2.0], "f4")
+    ui = buf.copy()
+    ui.user_strength = float(rng.uniform(0.5, 2.0))
+    ui.set_user_input(applied_force=tuple(rng.uniform(-0.1, 0.1, 2)), mouse_pos=tuple(rng.uniform(0, bounds, 2)),
+                      mouse_vel=tuple(rng.uniform(-5, 5, 2)), mouse_active=False)
+    return buf, bounds, consts, ui.user_input_bytes(), int(rng.choice([0, 128, 512])), int(rng.choice([0, 0, 3, 5]))
+
+
+BLOCKED_SUBSTEPS = {}
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(NGRID // 2, 1)))
+def test_random_quiet_scene_hybrid_equals_oracle(sb, oracle, seed):
+    """Seeded fuzzing of the hybrid path against the oracle's grid mode (itself the all-pairs scan, bit for bit): substep runs and
+    frames with delete passes, read back and compared at every checkpoint."""
+    buf, bounds, consts, ui, tile, K = make_quiet_case(sb, seed)
+    eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams,
+                    collision_mode=GRID, tile_particles=tile, block_substeps=K)
+    ref = oracle.OracleEngine(bounds, 10.0, 64, 2, GRID, threads=8)
+    for e in (eng, ref):
+        e.write_buffers(buf)
+        e.write_user_input(ui)
+        e.set_physics_constants(consts)
+    for k in range(5):
+        n = 90 + 37 * k
+        eng.step(n)
+        ref.step(n)
+        if k % 2:
+            for _ in range(2):
+                eng.frame()
+                ref.frame()
+        got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+        assert np.isfinite(exp.particles[:exp.particle_count]).all(), "seed %d is not a finite case" % seed
+        assert (got.particle_count, got.beam_count) == (exp.particle_count, exp.beam_count)
+        assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")), "seed %d chunk %d" % (seed, k)
+        assert got.beams.tobytes() == exp.beams.tobytes(), "seed %d chunk %d beams" % (seed, k)
+        assert np.array_equal(got.mapping, exp.mapping)
+    BLOCKED_SUBSTEPS[seed] = (eng.info("hybrid_substeps"), eng.info("substeps_done"), eng.info("hybrid_failed"), eng.info("hybrid_launches"))
+    eng.destroy()
+
+
+def test_the_quiet_scenes_really_ran_blocked():
+    """(after the cases above) a good part of those substeps went through tracked blocked launches, some were refused and redone"""
+    if not BLOCKED_SUBSTEPS:
+        pytest.skip("the hybrid fuzz cases did not run in this session")
+    blocked = sum(v[0] for v in BLOCKED_SUBSTEPS.values())
+    done = sum(v[1] for v in BLOCKED_SUBSTEPS.values())
+    engaged = sum(1 for v in BLOCKED_SUBSTEPS.values() if v[0] > 0)
+    print("hybrid fuzz: %d of %d substeps in blocked launches, %d of %d cases engaged, %d launches validated, %d refused"
+          % (blocked, done, engaged, len(BLOCKED_SUBSTEPS), sum(v[3] for v in BLOCKED_SUBSTEPS.values()),
+             sum(v[2] for v in BLOCKED_SUBSTEPS.values())))
+    assert engaged * 2 >= len(BLOCKED_SUBSTEPS) and blocked * 5 >= done
