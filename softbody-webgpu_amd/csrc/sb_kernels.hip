@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 // over the particles, 70-90 us per build; tools/grid_phases.py.)
 // Decision state and the displacement slots are double buffered by substep parity: this launch reads
 // ctl[par] / blk_max[par] and publishes ctl[par^1]; the particle kernel that follows fills blk_max[par^1].
-#define SB_MAINTAIN_BLOCKS 64u // (measured on the 1 M pile: 64 -> 41.5, 128 -> 42.2, 256..1024 -> 44.7-45.0 us per substep;
+#define SB_MAINTAIN_BLOCKS 128u // (r03, pile / soup: 32 -> 38.9 / 57.4, 64 -> 37.7 / 53.9, 128 -> 37.3 / 52.8 us per substep; r02: 64 -> 41.5, 128 -> 42.2, 256..1024 -> 44.7-45.0;
                               // the launch runs on every substep and only rebuilds on one in 4-14)
 #ifndef SB_MT
 #define SB_MT 1024u // threads per workgroup of k_grid_maintain
