@@ -589,13 +589,16 @@ __global__ __launch_bounds__(256) void k_hybrid_to_blocked(const float *__restri
 __global__ __launch_bounds__(256) void k_hybrid_to_tiled(const float *__restrict__ b_target, const float *__restrict__ b_last,
                                                          const float *__restrict__ b_strain, const float *__restrict__ b_stress,
                                                          uint32_t *b_broken, const uint32_t *__restrict__ g_of_copy, uint32_t nc,
-                                                         float *t_target, float *t_last, float *t_strain, float *t_stress,
-                                                         uint32_t *t_broken, int aux)
+                                                         const uint32_t *__restrict__ t_pair, float *t_target, float *t_last,
+                                                         float *t_strain, float *t_stress, uint32_t *t_broken, int aux)
 {
     const uint32_t cpy = blockIdx.x * 256u + threadIdx.x;
     if (cpy >= nc) return;
     const uint32_t g = g_of_copy[cpy];
     if (g == 0xFFFFFFFFu) return; // padding copy
+    // a copy a delete pass has removed keeps the record it died with (that is what a read-back returns for its data index): the
+    // blocked layout's slot of that beam holds whatever its dummy entry computed, or a strain from before its last single substeps
+    if (t_pair[cpy] == 0xFFFFFFFFu) return;
     t_target[cpy] = b_target[g];
     t_last[cpy] = b_last[g];
     if (aux) {
@@ -755,7 +758,7 @@ void sbk_hybrid_to_tiled(sb_engine *e, bool aux)
     SbBlockedDev &h = e->hy;
     if (!e->nbeam) return;
     k_hybrid_to_tiled<<<cdiv_b(e->nbeam, 256), 256, 0, e->stream>>>(h.d_target[h.cur], h.d_last[h.cur], h.d_strain, h.d_stress, h.d_broken,
-                                                                   h.d_g_of_copy, e->nbeam, e->beams.target, e->beams.last,
+                                                                   h.d_g_of_copy, e->nbeam, e->beams.pair, e->beams.target, e->beams.last,
                                                                    e->beams.strain, e->beams.stress, e->d_broken, aux ? 1 : 0);
 }
 // `count` launches of the depths in ks[], each followed by its validation; nothing here waits
