@@ -249,3 +249,74 @@ def test_the_quiet_scenes_really_ran_blocked():
           % (blocked, done, engaged, len(BLOCKED_SUBSTEPS), sum(v[3] for v in BLOCKED_SUBSTEPS.values()),
              sum(v[2] for v in BLOCKED_SUBSTEPS.values())))
     assert engaged * 2 >= len(BLOCKED_SUBSTEPS) and blocked * 10 >= done
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(NGRID // 4, 1)))
+def test_random_upload_sequences_keep_or_replan(sb, oracle, seed):
+    """One engine, a random sequence of uploads: the same topology with everything else changed (the plan is kept), the state just
+    read back (beams gone: planned again), another scene of the same capacity, the same buffers twice -- each followed by substeps
+    and frames and compared with a fresh oracle.  Collisions off (blocked plan) or on (tiling + hybrid), tiled or atomic path."""
+    rng = np.random.default_rng(7000 + seed)
+    mode = GRID if rng.integers(0, 2) else OFF
+    path = 2 if rng.integers(0, 4) else 1
+    make = make_quiet_case if mode == GRID else make_beam_case
+    scenes = [make(sb, 10 * seed + j) for j in range(2)]
+    cap_p = max(s[0].max_particles for s in scenes) + 4
+    cap_b = max(s[0].max_beams for s in scenes) + 4
+    bounds = max(s[1] for s in scenes)
+
+    def fit(b):   # the same scene in buffers of the engine's capacity
+        out = sb.Buffers(2, cap_p, cap_b)
+        out.set_scene(b.particles[:b.particle_count], b.beams[:b.beam_count])
+        return out
+
+    eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=cap_p, max_beams=cap_b, collision_mode=mode, path=path,
+                    tile_particles=int(rng.choice([0, 64, 256])))
+    cur = fit(scenes[0][0])
+    last_read = None
+    kept_expected = 0
+    for step in range(6):
+        what = int(rng.integers(0, 4)) if step else 0
+        if what == 1 and last_read is not None:
+            cur = last_read                                   # what the engine returned last time (maybe fewer beams)
+        elif what == 2:
+            cur = fit(scenes[int(rng.integers(0, 2))][0])     # a scene from scratch
+        elif what == 3 or (what == 1 and last_read is None):
+            cur = cur.copy()                                  # same topology, everything that may move moved
+            P, B = cur.particle_count, cur.beam_count
+            cur.particles[:P, :2] += rng.uniform(-0.4, 0.4, (P, 2)).astype("f4")
+            cur.particles[:P, 2:4] += rng.uniform(-2, 2, (P, 2)).astype("f4")
+            m = cur.mapping[cur.max_particles:cur.max_particles + B].astype(np.int64)
+            cur.beams["last_length"][m] *= rng.uniform(0.99, 1.01, B).astype("f4")
+            pick = rng.random(B) < 0.1
+            cur.beams["target_length"][m[pick]] *= np.float32(1.005)
+        ref = oracle.OracleEngine(bounds, 10.0, 64, 2, mode, threads=8)
+        consts, ui = scenes[0][2], scenes[0][3]
+        for e in (eng, ref):
+            e.write_buffers(cur)
+            e.write_user_input(ui)
+            e.set_physics_constants(consts)
+        n = int(rng.integers(5, 60))
+        eng.step(n); ref.step(n)
+        if rng.integers(0, 2):
+            eng.frame(); ref.frame()
+        got, exp = eng.load_buffers(cur.copy()), ref.load_buffers(cur.copy())
+        if not np.isfinite(exp.particles[:exp.particle_count]).all():
+            break
+        assert (got.particle_count, got.beam_count) == (exp.particle_count, exp.beam_count), "seed %d upload %d" % (seed, step)
+        assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")), "seed %d upload %d (kind %d)" % (seed, step, what)
+        assert got.beams.tobytes() == exp.beams.tobytes(), "seed %d upload %d (kind %d) beams" % (seed, step, what)
+        assert np.array_equal(got.mapping, exp.mapping)
+        last_read = got
+    UPLOADS_KEPT[seed] = eng.info("uploads_kept")
+    eng.destroy()
+
+
+UPLOADS_KEPT = {}
+
+
+def test_some_of_those_uploads_kept_their_plan():
+    if not UPLOADS_KEPT:
+        pytest.skip("the upload-sequence cases did not run in this session")
+    print("upload sequences: %d uploads kept the plan in %d cases" % (sum(UPLOADS_KEPT.values()), len(UPLOADS_KEPT)))
+    assert sum(UPLOADS_KEPT.values()) >= len(UPLOADS_KEPT) // 2
