@@ -12,13 +12,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,depth,path", [(2, 4, 2), (3, 8, 2), (2, 2, 1)])
-def test_simulated_gpu_ranks_equal_single_engine(sb, world, depth, path):
+@pytest.mark.parametrize("world,depth,path,yield_strain", [(2, 4, 2, 0.2), (3, 8, 2, 0.2), (2, 2, 1, 0.2), (2, 5, 2, 0.004), (3, 7, 2, 0.004)])
+def test_simulated_gpu_ranks_equal_single_engine(sb, world, depth, path, yield_strain):
+    """(yield_strain 0.004: beams yield all over the lattice when it lands, ghost copies receive their owners' new targets with every
+    refresh -- the tiles they sit in stop being "never yielded" for the blocked kernel, sb_kernels.hip k_halo_unpack)"""
     import torch
     from halo_oracle import LocalBus, step_all
     halo = sb.halo
     W, H, steps = 40, 48, 100
-    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.5)
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.5, yield_strain=yield_strain)
     bounds = 8000.0
 
     def engine_for(buf):
@@ -32,6 +34,9 @@ def test_simulated_gpu_ranks_equal_single_engine(sb, world, depth, path):
     ref.step(steps)
     want = ref.load_buffers(gbuf.copy())
     ref.destroy()
+    if yield_strain < 0.1:
+        B = want.beam_count
+        assert (want.beams["target_length"][:B] != want.beams["length"][:B]).mean() > 0.02, "the scene is meant to yield"
 
     dev = torch.device("cuda", 0)
     bus = LocalBus()
