@@ -13,7 +13,7 @@ for case in range(40):
     world = int(rng.integers(2, 4)); depth = int(rng.integers(2, 9)); path, block = [(2, 0), (2, 1), (1, 0), (2, 3)][int(rng.integers(0, 4))]
     W, H, frames = int(rng.integers(max(depth, 10), 40)), int(rng.integers(10, 40)), int(rng.integers(1, 4))
     kw = dict(d=30.0, origin=(100.0, 11.5), jitter=float(rng.uniform(0.2, 2.0)), velocity=(float(rng.uniform(-8, 8)), float(rng.uniform(-9, -1))),
-              strain_limit=float(rng.choice([0.01, 0.02, 0.04, 0.08])))
+              strain_limit=float(rng.choice([0.01, 0.02, 0.04, 0.08])), yield_strain=float(rng.choice([0.2, 0.2, 0.004, 0.01])))
     def engine_for(buf):
         e = sb.Engine(bounds_size=8000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=0, path=path,
                       tile_particles=int(rng.choice([64, 256, 0])), block_substeps=block)
