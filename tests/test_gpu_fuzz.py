@@ -167,14 +167,15 @@ def make_quiet_case(sb, seed):
     limits in reach; random tile size, block depth, constants and user input.  The engine's hybrid path goes
     blocked while the closest listed pair stays clear, back to single substeps when somebody is about to touch."""
     rng = np.random.default_rng(9000 + seed)
-    bounds = float(rng.choice([1600.0, 3000.0]))
-    square = 420.0
+    scale = float(os.environ.get("SB_FUZZ_SCALE", "1"))      # (soak runs: 6 makes blobs of up to 80 x 80 particles, many tiles each)
+    bounds = float(rng.choice([1600.0, 3000.0])) * scale
+    square = 420.0 * scale
     side = int((bounds - 40.0) // square)
     squares = rng.permutation(side * side)[: int(rng.integers(2, min(9, side * side)))]
     parts, beams, base = [], [], 0
     for sq in squares:
         d = float(rng.uniform(24.0, 34.0))
-        w, h = int(rng.integers(3, int(360.0 // d))), int(rng.integers(3, int(360.0 // d)))
+        w, h = int(rng.integers(3, int(360.0 * scale // d))), int(rng.integers(3, int(360.0 * scale // d)))
         ox, oy = 30.0 + (sq % side) * square + rng.uniform(0, 20), 30.0 + (sq // side) * square + rng.uniform(0, 20)
         p, b = sb.scenes.rectangle(ox, oy, d, w, h, float(rng.choice([3, 50, 500])), float(rng.choice([50, 700])),
                                    float(rng.choice([0.02, 0.2, 2.0])), float(rng.choice([0.1, 0.5, 1e9])), base=base,
