@@ -97,10 +97,11 @@ def make_beam_case(sb, seed):
     """Collisions off (the temporally blocked kernel's domain): several lattice blobs of different shapes and materials,
     some joined by long beams (rings then grow across blobs), with yield and break limits in reach, random constants."""
     rng = np.random.default_rng(5000 + seed)
-    bounds = float(rng.choice([1000.0, 1600.0, 3000.0]))
+    scale = int(os.environ.get("SB_FUZZ_SCALE", "1"))      # (soak runs: blobs of up to 24 * scale particles a side, many tiles each)
+    bounds = float(rng.choice([1000.0, 1600.0, 3000.0])) * scale
     parts, beams, base, anchors = [], [], 0, []
     for _ in range(int(rng.integers(2, 7))):
-        w, h = int(rng.integers(2, 24)), int(rng.integers(2, 24))
+        w, h = int(rng.integers(2, 24 * scale)), int(rng.integers(2, 24 * scale))
         d = float(rng.uniform(12.0, 40.0))
         ox, oy = rng.uniform(20, max(21.0, bounds - 20 - w * d)), rng.uniform(20, max(21.0, bounds - 20 - h * d))
         p, b = sb.scenes.rectangle(ox, oy, d, w, h, float(rng.choice([1, 3, 50, 500])), float(rng.choice([10, 50, 700])),
