@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 BOUNDS = 4000.0
 
 
-def breaking_lattice(sb, *, distinct_lengths=False):
+def breaking_lattice(sb, *, distinct_lengths=False, layout=2):
     """A 40 x 30 lattice thrown into the corner: yields, breaks beams, delete passes remove them."""
     buf = sb.scenes.lattice_buffers(40, 30, d=30.0, origin=(30.0, 30.0), spring=50.0, damp=100.0, yield_strain=0.05, strain_limit=0.12,
-                                    layout=2, velocity=(-40.0, -35.0), slack=8, jitter=0.5)
+                                    layout=layout, velocity=(-40.0, -35.0), slack=8, jitter=0.5)
     if distinct_lengths:  # material mode 1: every beam its own rest length (as the reference's editor makes them)
         buf = sb.scenes.rest_at_current_length(buf)
     return buf
@@ -80,6 +80,28 @@ def test_same_topology_keeps_the_plan(sb, oracle, mode, path, distinct):
     got4, exp4 = play(eng, ref, moved(got, 9))
     assert eng.info("uploads_kept") == 4
     assert_same(got4, exp4, "read-back topology, moved")
+    eng.destroy()
+
+
+@pytest.mark.parametrize("mode", [OFF, GRID])
+def test_same_topology_in_the_reference_layout(sb, oracle, mode):
+    """Layout 1 (the reference's own bytes: u16 endpoints packed in one word, u16 mapping): the comparison of the records and the
+    state that travels read the other record format."""
+    first = breaking_lattice(sb, layout=1)
+    eng = sb.Engine(bounds_size=BOUNDS, layout=1, max_particles=first.max_particles, max_beams=first.max_beams, collision_mode=mode)
+    ref = oracle.OracleEngine(BOUNDS, 10.0, 64, 1, mode, threads=8)
+    got, exp = play(eng, ref, first)
+    assert exp.beam_count < first.beam_count
+    assert_same(got, exp, "layout 1, first upload")
+    second = moved(first, 5)
+    got2, exp2 = play(eng, ref, second)
+    assert eng.info("uploads_kept") == 1
+    assert_same(got2, exp2, "layout 1, same topology")
+    third = second.copy()
+    third.beams["b"][3] = (int(third.beams["b"][3]) + 2) % third.particle_count   # another endpoint: planned again
+    got3, exp3 = play(eng, ref, third)
+    assert eng.info("uploads_kept") == 1
+    assert_same(got3, exp3, "layout 1, endpoint changed")
     eng.destroy()
 
 
