@@ -201,8 +201,8 @@ def make_quiet_case(sb, seed):
     ui = buf.copy()
     ui.user_strength = float(rng.uniform(0.5, 2.0))
     ui.set_user_input(applied_force=tuple(rng.uniform(-0.1, 0.1, 2)), mouse_pos=tuple(rng.uniform(0, bounds, 2)),
-                      mouse_vel=tuple(rng.uniform(-5, 5, 2)), mouse_active=False)
-    return buf, bounds, consts, ui.user_input_bytes(), int(rng.choice([0, 128, 512])), int(rng.choice([0, 0, 3, 5]))
+                      mouse_vel=tuple(rng.uniform(-5, 5, 2)), mouse_active=bool(rng.integers(0, 3) == 0))   # (one case in three: the
+    return buf, bounds, consts, ui.user_input_bytes(), int(rng.choice([0, 128, 512])), int(rng.choice([0, 0, 3, 5]))  # particle phase with the mouse terms)
 
 
 BLOCKED_SUBSTEPS = {}
