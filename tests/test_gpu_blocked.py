@@ -85,6 +85,19 @@ def test_negative_yield_takes_the_single_substep_kernel(sb, oracle):
     assert_same(got, exp, "negative yield")
 
 
+@pytest.mark.parametrize("spring,damp,blocked", [(1.0e-20, 700.0, False), (50.0, 1.0e32, False), (0.0, 700.0, True), (-50.0, 700.0, True),
+                                                 (3.0e-15, 1.0e-14, True), (2.0e29, 0.0, True)])
+def test_springs_at_the_edges_of_the_exact_range(sb, oracle, spring, damp, blocked):
+    """The blocked kernel multiplies the force scale 65536 into spring and damp (one packed multiplication less per beam): exact
+    for zero and for magnitudes between 2^-50 and 2^100 -- negative ones included -- and anything else takes the single-substep
+    kernel.  Either way the oracle's bits (forces that saturate the fixed-point sums included: spring 2e29)."""
+    buf = sb.scenes.lattice_buffers(24, 20, d=25.0, origin=(100.0, 100.0), jitter=2.0, layout=2, spring=spring, damp=damp,
+                                    yield_strain=0.3, strain_limit=1e9, velocity=(0.5, -1.0))
+    got, exp, info = both(sb, oracle, buf, K=5, n=23)
+    assert (info["substeps_per_launch"] > 1) == blocked, info
+    assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")) and got.beams.tobytes() == exp.beams.tobytes()
+
+
 def test_fallback_with_automatic_tile_size_keeps_the_particle_order(sb, oracle):
     """The blocked plan picks its own tile size (here 256-particle tiles for 90 000 particles); when the scene then turns out
     not to fit the blocked kernel (negative yield), the single-substep tiling must be made on the SAME bisection -- the
