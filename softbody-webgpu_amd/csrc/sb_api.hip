@@ -784,14 +784,14 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
     SB_HIP(e, hipMemsetAsync(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4, e->stream));
     e->delete_gen = 0;
     if (e->opt.collision_mode == SB_COLLIDE_GRID && e->d_grid_ctl) { // the hash: no build yet, same frame
-        SB_HIP(e, hipMemsetAsync(e->d_head, 0, e->grid_heads * 8, e->stream));
-        for (int k = 0; k < 2; k++) SB_HIP(e, hipMemsetAsync(e->d_blk_max[k], 0, e->grid_slots * 4, e->stream));
-        SB_HIP(e, hipMemsetAsync(e->d_grid_done, 0, 4, e->stream));
-        SB_HIP(e, hipMemsetAsync(e->d_grid_outside, 0, 8, e->stream));
+        for (int k = 0; k < 2; k++) SB_HIP(e, hipMemsetAsync(e->d_head[k], 0, e->grid_heads * 8, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_blk_max, 0, e->grid_slots * 4, e->stream));
+        SB_HIP(e, hipMemsetAsync(e->d_grid_outside, 0, 16, e->stream));
         SB_HIP(e, hipMemsetAsync(e->d_nl_count, 0, std::max<size_t>(P, 1) * 4, e->stream));
         SB_HIP(e, hipMemcpyAsync(e->d_grid_ctl, e->grid_ctl0, sizeof e->grid_ctl0, hipMemcpyHostToDevice, e->stream));
         e->grid_par = 0;
-        e->grid.ctl = &e->d_grid_ctl[0];
+        e->grid_force = true;
+        e->grid_classic_left = e->grid_classic_chunk = e->grid_calm = e->grid_executed = 0;
     }
     memcpy(&e->consts, md + 48, sizeof(SbConsts));
     SB_HIP(e, hipStreamSynchronize(e->stream));
@@ -1192,52 +1192,54 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid.bounds = S;
         e->grid.wide_side = std::max(1u, (uint32_t)std::floor(std::sqrt((double)e->ncell)));
         const size_t n1 = (size_t)e->ncell + 1;
-        SB_TRY(dev_alloc(e, &e->d_head, n1));
-        SB_HIP(e, hipMemset(e->d_head, 0, n1 * 8)); // build number 0: "never written" (the first build is number 1)
-        SB_TRY(dev_alloc(e, &e->d_rec, P));
-        SB_TRY(dev_alloc(e, &e->d_cell_of, P));
-        SB_TRY(dev_alloc(e, &e->d_grid_ctl, 2));
-        const size_t nblk = std::max<size_t>(e->ntiles, (P + 255) / 256) + 1;
-        for (int k = 0; k < 2; k++) {
-            SB_TRY(dev_alloc(e, &e->d_blk_max[k], 3 * nblk)); // max | sum dx | sum dy per workgroup
-            SB_HIP(e, hipMemset(e->d_blk_max[k], 0, 3 * nblk * 4));
+        for (int k = 0; k < 2; k++) { // two hash buffers (SbGrid: the lagged schedule pushes the next one while the current one is still scanned)
+            SB_TRY(dev_alloc(e, &e->d_head[k], n1));
+            SB_HIP(e, hipMemset(e->d_head[k], 0, n1 * 8)); // build number 0: "never written" (the first build is number 1)
+            SB_TRY(dev_alloc(e, &e->d_rec[k], P));
+            SB_TRY(dev_alloc(e, &e->d_cell_of[k], P));
         }
-        SB_TRY(dev_alloc(e, &e->d_grid_done, 1));
-        SB_HIP(e, hipMemset(e->d_grid_done, 0, 4));
-        SB_TRY(dev_alloc(e, &e->d_grid_outside, 2));
-        SB_HIP(e, hipMemset(e->d_grid_outside, 0, 8));
+        SB_TRY(dev_alloc(e, &e->d_grid_ctl, 2));
+        SB_TRY(dev_alloc(e, &e->d_blk_max, 3 * SB_GRID_SLOTS * 4)); // float4[3][SB_GRID_SLOTS]: max | sample dx | sample dy | -
+        SB_HIP(e, hipMemset(e->d_blk_max, 0, 3 * SB_GRID_SLOTS * 16));
+        SB_TRY(dev_alloc(e, &e->d_grid_outside, 4));
+        SB_HIP(e, hipMemset(e->d_grid_outside, 0, 16));
         SB_TRY(dev_alloc(e, &e->d_grid_nonempty, 1 + 1024)); // (the hybrid look's answer and the per-workgroup minima behind it)
         SbGridCtl ctl[2] = {};
         for (int k = 0; k < 2; k++) {
-            ctl[k].force = 1;
-            ctl[k].skin = ctl[k].skin_min = skin;
+            ctl[k].skin_min = skin;
             // grid_skin given explicitly: that skin, fixed.  Default: adaptive between 0.4 r and 1.6 r (SbGridCtl).
             ctl[k].skin_max = e->opt.grid_skin > 0.f ? skin : 4.0f * skin;
-            ctl[k].cell = cell;
-            ctl[k].nx = e->grid.nx_cap;
-            ctl[k].ny = e->grid.ny_cap;
-            ctl[k].x0 = x0;
-            ctl[k].y0 = y0;
-            ctl[k].wide = 0;
+            ctl[k].geo.skin = skin;
+            ctl[k].geo.cell = cell;
+            ctl[k].geo.nx = e->grid.nx_cap;
+            ctl[k].geo.ny = e->grid.ny_cap;
+            ctl[k].geo.x0 = x0;
+            ctl[k].geo.y0 = y0;
+            ctl[k].geo.wide = 0;
             const float reach = e->grid.two_r + 2.0f * skin;
-            ctl[k].reach2 = reach * reach * 1.001f;
+            ctl[k].geo.reach2 = reach * reach * 1.001f;
+            ctl[k].pgeo = ctl[k].geo;
             ctl[k].since = 1000; // "the hash before the first one lasted long": start lean
         }
         SB_HIP(e, hipMemcpy(e->d_grid_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
         memcpy(e->grid_ctl0, ctl, sizeof ctl);
         e->grid_heads = n1;
-        e->grid_slots = 3 * nblk;
+        e->grid_slots = 3 * SB_GRID_SLOTS * 4;
         e->grid_par = 0;
-        e->grid.head = e->d_head;
-        e->grid.rec = e->d_rec;
-        e->grid.cell_of = e->d_cell_of;
+        e->grid_force = true; // no hash yet: the first substep starts with a forced helper launch
+        e->grid_classic_left = e->grid_classic_chunk = e->grid_calm = e->grid_executed = 0;
+        e->grid.head = e->d_head[0];
+        e->grid.rec = e->d_rec[0];
+        e->grid.cell_of = e->d_cell_of[0];
+        e->grid.head1 = e->d_head[1];
+        e->grid.rec1 = e->d_rec[1];
+        e->grid.cell_of1 = e->d_cell_of[1];
         SB_TRY(dev_alloc(e, &e->d_nl_count, P));
         SB_TRY(dev_alloc(e, &e->d_nl, (size_t)SB_NL_CAP * std::max<size_t>(P, 1)));
         SB_HIP(e, hipMemset(e->d_nl_count, 0, std::max<size_t>(P, 1) * 4));
         e->grid.nl_count = e->d_nl_count;
         e->grid.nl = e->d_nl;
         e->grid.nl_stride = P;
-        e->grid.ctl = &e->d_grid_ctl[0];
     }
     tm.mark("spatial hash arrays");
     // ---- accumulators and masks, zeroed (engineWorker.ts:591-592)
@@ -1319,6 +1321,67 @@ sb_status sb_get_physics_constants(sb_engine *e, float c8[8])
     return SB_OK;
 }
 
+// m substeps, one launch each, with the collision loop served by the spatial hash (SbGridCtl, sb_physics.h).  In the lagged
+// schedule nothing but the substep kernels is launched; what the host owes that schedule is one look when the launches have
+// been issued: if a substep moved somebody farther than its predecessor predicted, the tail of that launch -- itself still a
+// correct substep -- raised `abort` and every launch behind it returned at once.  The host then takes the buffers back to what
+// the device really did, orders a hash of the current state from the helper launch, and runs a stretch in the classic schedule
+// (helper launch in front of every substep: violent scenes cost what they cost in r03), which doubles with every abort and
+// decays while the scene stays calm.
+// an abort has been seen (grid_substeps, or the hybrid's look): a hash of the current state from the helper, then a stretch in
+// the classic schedule that doubles with every abort
+static void grid_recover(sb_engine *e)
+{
+    e->grid_aborts++;
+    e->grid_calm = 0;
+    e->grid_force = true; // (the forced helper launch publishes a state without the flag)
+    e->grid_classic_chunk = std::min(std::max(16u, 2u * e->grid_classic_chunk), 1024u);
+    e->grid_classic_left = e->grid_classic_chunk;
+}
+
+static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
+{
+    if (!(e->opt.collision_mode == SB_COLLIDE_GRID && e->P && e->d_grid_ctl)) {
+        for (uint32_t i = 0; i < m; i++) sbk_launch_substep(e, aux_on_last && i + 1 == m);
+        return SB_OK;
+    }
+    while (m) {
+        const uint32_t sched = sbk_grid_mode(e);
+        const bool stretch = sched == SB_GRID_CLASSIC && e->grid_classic_left != 0u;
+        const uint32_t chunk = stretch ? std::min(m, e->grid_classic_left) : m, exec0 = e->grid_executed;
+        for (uint32_t i = 0; i < chunk; i++) sbk_launch_substep(e, aux_on_last && i + 1 == m);
+        if (sched == SB_GRID_CLASSIC) { // (its decisions never abort: the helper serves whatever they order)
+            if (stretch) e->grid_classic_left -= chunk;
+            e->grid_classic_substeps += chunk;
+            m -= chunk;
+            continue;
+        }
+        SbGridCtl *pin = (SbGridCtl *)(e->dev_err + 96); // (pinned; hybrid_substeps uses words 16 .. 95)
+        SB_HIP(e, hipMemcpyAsync(pin, e->d_grid_ctl, 2 * sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
+        SB_HIP(e, hipStreamSynchronize(e->stream));
+        if (!(pin[0].abort | pin[1].abort)) {
+            e->grid_calm += chunk;
+            if (e->grid_calm >= 1024u && e->grid_classic_chunk) { // calm for a while: the next abort starts with a shorter stretch
+                e->grid_classic_chunk /= 2u;
+                e->grid_calm = 0;
+            }
+            m -= chunk;
+            continue;
+        }
+        // the launches that ran are the ones that counted themselves; the rest returned at once
+        const uint32_t reached = std::max(pin[0].executed, pin[1].executed), ran = std::min(reached - exec0, chunk), undone = chunk - ran;
+        static const bool debug = getenv("SB_GRID_DEBUG") != nullptr;
+        if (debug) fprintf(stderr, "[sb grid] abort after %u of %u substeps (classic stretch %u)\n", ran, chunk, std::max(16u, 2u * e->grid_classic_chunk));
+        e->cur ^= undone & 1u;
+        e->grid_par ^= undone & 1u;
+        e->substeps_done -= undone;
+        e->grid_executed = exec0 + ran;
+        grid_recover(e);
+        m -= ran;
+    }
+    return SB_OK;
+}
+
 // n substeps.  strain/stress are pure outputs (render inputs in the reference, render.wgsl:82): only the last
 // substep before control returns to the caller can ever be observed, so only it stores them.
 // SB_COLLIDE_GRID with a blocked plan beside the tiling (e->hy).  The reference always runs its collision loop
@@ -1372,27 +1435,34 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
     while (n) {
         if (h.slow_left || n < 2u) {
             const uint32_t m = h.slow_left ? std::min(n, h.slow_left) : n;
-            for (uint32_t i = 0; i < m; i++) sbk_launch_substep(e, i + 1 == n);
+            SB_TRY(grid_substeps(e, m, m == n));
             h.slow_left -= std::min(h.slow_left, m);
             n -= m;
             continue;
         }
         // ---- look
         struct Look { SbGridCtl ctl; float min_d2; } *look = (Look *)(e->dev_err + 16); // (pinned; words 0..15 are the error and stamp words)
+        sbk_launch_grid_settle(e); // the next substep's decision ahead of time: the bound then covers the substep just done
         SB_HIP(e, hipMemcpyAsync(&look->ctl, e->d_grid_ctl + e->grid_par, sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
         sbk_launch_lists_min_d2(e); // (asked only here, by kernels of its own)
         SB_HIP(e, hipMemcpyAsync(&look->min_d2, e->d_grid_nonempty, 4, hipMemcpyDeviceToHost, e->stream));
         SB_HIP(e, hipStreamSynchronize(e->stream));
         const SbGridCtl ctl = look->ctl;
-        auto force_rebuild = [&]() -> sb_status { // the next maintenance launch rebuilds the hash, the substep after it makes the lists
-            for (int par = 0; par < 2; par++) SB_HIP(e, hipMemsetAsync(&e->d_grid_ctl[par].force, 0x01, 4, e->stream));
-            h.slow_left = std::min<uint32_t>(n, 2u);
+        auto force_rebuild = [&]() -> sb_status { // the next substep starts with a forced helper launch and makes the lists
+            e->grid_force = true;
+            h.slow_left = std::min<uint32_t>(n, 1u);
             return SB_OK;
         };
-        if (ctl.force != 0u || ctl.builds == 0u) { // no hash yet, or one on order: two substeps make it and its lists
-            h.slow_left = std::min<uint32_t>(n, 2u);
+        if (ctl.abort != 0u) { // (the settling launch found the lists not known to be valid any more: as in grid_substeps)
+            grid_recover(e);
+            h.slow_left = std::min<uint32_t>(n, 1u);
             continue;
         }
+        if (e->grid_force || ctl.builds == 0u || ctl.fresh != 0u || ctl.need_build != 0u || ctl.pushing != 0u) {
+            h.slow_left = std::min<uint32_t>(n, ctl.pushing ? 2u : 1u); // no hash yet, or lists on order: a substep or two make them
+            continue;
+        }
+        const float skin = ctl.geo.skin;
         // Nobody within 2r + 2 skin of anybody (every list empty): no contact while the hash's bound stays inside its skin.
         // Somebody listed, the closest such pair d apart: two particles approach each other by at most twice the displacement
         // bound (it is measured against a common drift), so no LISTED pair touches either while the bound grows by less than
@@ -1400,17 +1470,17 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         float gap = INFINITY;
         if (look->min_d2 < INFINITY) gap = 0.5f * ((float)(std::sqrt((double)look->min_d2) * (1.0 - 1.0e-6)) - e->grid.two_r);
         if (!(gap > 0.0f)) gap = 0.0f; // (NaN, or in contact)
-        const float budget = std::min(ctl.skin - ctl.accum, gap);
+        const float budget = std::min(skin - ctl.accum, gap);
         static const bool debug = getenv("SB_HYBRID_DEBUG") != nullptr;
         if (debug)
             fprintf(stderr, "[sb hybrid] look: n %u builds %u accum %g skin %g since %u closest listed pair %g gap %g budget %g K %u pending %d\n", n,
-                    ctl.builds, ctl.accum, ctl.skin, ctl.since, std::sqrt((double)look->min_d2), gap, budget, h.K, e->hy_pending ? 1 : 0);
-        if (e->n_ghost_p != 0 || e->n_send_p != 0 || !(gap >= 0.15f * ctl.skin)) { // somebody (nearly) touching, or ghost zones (not handled here)
+                    ctl.builds, ctl.accum, skin, ctl.since, std::sqrt((double)look->min_d2), gap, budget, h.K, e->hy_pending ? 1 : 0);
+        if (e->n_ghost_p != 0 || e->n_send_p != 0 || !(gap >= 0.15f * skin)) { // somebody (nearly) touching, or ghost zones (not handled here)
             h.slow_chunk = std::min<uint32_t>(std::max<uint32_t>(16u, 2u * h.slow_chunk), 1024u);
             h.slow_left = std::min(n, h.slow_chunk);
             continue;
         }
-        if (!(budget >= 0.15f * ctl.skin)) { // quiet, but little of the skin left: a fresh hash is cheaper than a run that fails
+        if (!(budget >= 0.15f * skin)) { // quiet, but little of the skin left: a fresh hash is cheaper than a run that fails
             SB_TRY(force_rebuild());
             continue;
         }
@@ -1433,8 +1503,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         if (!h.K) { // quiet for the first time: now the plan is worth having on the device
             SB_TRY(hybrid_materialise(e));
             if (!h.K) { // (the scene cannot use one after all: more material rows than an entry word holds, a negative yield ...)
-                for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
-                return SB_OK;
+                return grid_substeps(e, n, true);
             }
         }
         // ---- a run of tracked launches
@@ -1451,11 +1520,11 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         q.Cy = ctl.Cy;
         q.cx = ctl.cx;
         q.cy = ctl.cy;
-        q.skin = std::min(ctl.skin, ctl.accum + gap); // (the validation's limit for the bound: the skin, or the gap of the closest listed pair)
+        q.skin = std::min(skin, ctl.accum + gap); // (the validation's limit for the bound: the skin, or the gap of the closest listed pair)
         q.fail_at = 0xFFFFFFFFu;
         if (fail_every && (h.launches_ok + h.launches_failed + count) / fail_every != (h.launches_ok + h.launches_failed) / fail_every)
             q.fail_at = fail_every - 1u - (uint32_t)((h.launches_ok + h.launches_failed) % fail_every); // (tests: a roll-back every so many launches)
-        SbHybridCtl *pin = (SbHybridCtl *)(e->dev_err + 48);
+        SbHybridCtl *pin = (SbHybridCtl *)(e->dev_err + 64);
         *pin = q;
         SB_HIP(e, hipMemcpyAsync(h.d_q, pin, sizeof q, hipMemcpyHostToDevice, e->stream));
         sbk_hybrid_to_blocked(e);
@@ -1474,8 +1543,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         h.launches_ok += done;
         h.substeps_blocked += q.substeps;
         if (q.substeps) h.rate = std::max(q.D - ctl.accum, 0.0f) / (float)q.substeps;
-        // the hash's bookkeeping, as if its maintenance launch had run on every one of those substeps; the displacement
-        // slots that launch reads next are from before the run (any drift estimate keeps the bound valid: zero)
+        // the hash's bookkeeping, as if the tails of single substeps had kept it all along
         SbGridCtl upd = ctl;
         upd.accum = q.D;
         upd.Cx = q.Cx;
@@ -1483,10 +1551,11 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         upd.cx = q.cx;
         upd.cy = q.cy;
         upd.since = ctl.since + q.substeps;
+        upd.settled = 1u; // (the next substep adopts this block as it stands)
         look->ctl = upd;
         SB_HIP(e, hipMemcpyAsync(e->d_grid_ctl + e->grid_par, &look->ctl, sizeof(SbGridCtl), hipMemcpyHostToDevice, e->stream));
-        SB_HIP(e, hipMemsetAsync(e->d_blk_max[e->grid_par], 0, 3 * (size_t)(std::max<size_t>(e->ntiles, ((size_t)e->P + 255) / 256) + 1) * 4, e->stream));
         SB_HIP(e, hipStreamSynchronize(e->stream)); // (`look` is reused by the next look)
+        if (!(upd.accum + 2.0f * h.rate <= skin)) e->grid_force = true; // the run used the skin up: single substeps start on a fresh hash
         n -= q.substeps;
         if (done < count) { // over the budget (or told to fail, by a test): a fresh hash, then look again -- after a stretch of
             h.launches_failed += 1; // single substeps that doubles with every refusal in a row (a scene that keeps using its budget up
@@ -1505,8 +1574,7 @@ static sb_status launch_substeps(sb_engine *e, uint32_t n)
 {
     if (e->bk.K) sbk_launch_blocked(e, n, true);
     else if (e->hy.K || e->hy_pending) return hybrid_substeps(e, n);
-    else
-        for (uint32_t i = 0; i < n; i++) sbk_launch_substep(e, i + 1 == n);
+    else return grid_substeps(e, n, true);
     return SB_OK;
 }
 
@@ -1784,8 +1852,12 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "substeps_done") *value = e->substeps_done;
     else if (k == "lds_bytes") *value = e->lds_bytes;
     else if (k == "uploads_kept") *value = e->uploads_kept;
-    else if (k == "kernels_per_substep")
-        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID ? 1 : 0);
+    else if (k == "kernels_per_substep") // (the hash's helper launch runs in the classic schedule only: sb_physics.h SbGridCtl)
+        *value = (e->path == SB_PATH_TILED ? 1 : 2) + (e->opt.collision_mode == SB_COLLIDE_GRID && sbk_grid_mode(e) == SB_GRID_CLASSIC ? 1 : 0);
+    else if (k == "grid_aborts") *value = e->grid_aborts;                   // lagged launches whose tail found the lists not known to be valid any more (host recovery)
+    else if (k == "grid_helper_launches") *value = e->grid_helper_launches; // k_grid_build launches since the engine was created
+    else if (k == "grid_classic_substeps") *value = e->grid_classic_substeps; // substeps run in the classic schedule (helper launch in front)
+    else if (k == "grid_schedule") *value = sbk_grid_mode(e);               // 0 lagged, 1 classic: what the next substep would run
     else if (k == "grid_cells") *value = e->ncell;
     else if (k == "grid_builds") {
         *value = 0;
@@ -1802,7 +1874,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             SbGridCtl ctl;
             SB_HIP(e, hipStreamSynchronize(e->stream));
             SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
-            *value = ctl.wide;
+            *value = ctl.geo.wide;
         }
     }
     else if (k == "grid_skin_x1000") { // the skin of the current hash, in thousandths of a unit (it adapts)
@@ -1811,7 +1883,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             SbGridCtl ctl;
             SB_HIP(e, hipStreamSynchronize(e->stream));
             SB_HIP(e, hipMemcpy(&ctl, e->d_grid_ctl + e->grid_par, sizeof ctl, hipMemcpyDeviceToHost));
-            *value = (uint64_t)(ctl.skin * 1000.0f + 0.5f);
+            *value = (uint64_t)(ctl.geo.skin * 1000.0f + 0.5f);
         }
     }
     else if (k == "beams_flagged") { // beams flagged by mark_beam_deleted (compute.wgsl:117-121) since the last delete pass

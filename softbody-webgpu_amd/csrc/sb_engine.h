@@ -178,21 +178,25 @@ struct sb_engine {
     uint32_t nmat = 0;
     float *d_mat = nullptr;   // [nmat][6] = length, spring, damp, yield_strain, strain_break_limit, 1/length
 
-    // spatial hash (SB_COLLIDE_GRID), rebuilt from the READ state when the displacement bound demands it
+    // spatial hash (SB_COLLIDE_GRID): two hash buffers, the decision state, what the particle kernels' tails need (sb_physics.h SbGridCtl)
     SbGrid grid{};
     uint32_t ncell = 0;               // nx*ny (+1 spare entry in the per-cell arrays)
-    unsigned long long *d_head = nullptr; // per cell: (build number << 32) | first record of its list (SbGrid::head)
-    uint32_t *d_cell_of = nullptr;    // per particle: cell at the last build
-    float4 *d_rec = nullptr;          // per particle: {x, y at the build, slot, next record of its cell's list}
-    SbGridCtl *d_grid_ctl = nullptr;  // [2] rebuild decision state by substep parity (device resident: no host sync per substep)
-    uint32_t *d_blk_max[2] = {};      // per workgroup of the particle kernel: largest displacement (float bits), by parity
+    unsigned long long *d_head[2] = {}; // per cell: (build number << 32) | first record of its list (SbGrid::head)
+    uint32_t *d_cell_of[2] = {};      // per particle: cell at that buffer's last build
+    float4 *d_rec[2] = {};            // per particle: {x, y at the build, slot, next record of its cell's list}
+    SbGridCtl *d_grid_ctl = nullptr;  // [2] decision state by substep parity (device resident: no host sync per substep)
+    uint32_t *d_blk_max = nullptr;    // float4[3][SB_GRID_SLOTS]: what the particle kernels measure (sb_physics.h SbGridStep), by substep number % 3
     uint32_t *d_nl_count = nullptr, *d_nl = nullptr; // neighbour lists (SbGrid)
     uint32_t *d_grid_nonempty = nullptr; // sbk_launch_lists_min_d2: [0] = squared distance of the closest listed pair (+inf: every list empty), [1 ..] per-workgroup minima
-    uint32_t *d_grid_outside = nullptr; // particles the hash build in progress found outside its frame (zero between builds)
-    uint32_t *d_grid_done = nullptr;  // workgroups of the hash build in progress that have finished (zero between builds)
-    uint32_t grid_par = 0;            // parity the next k_grid_maintain reads
+    uint32_t *d_grid_outside = nullptr; // [4] particles each hash build found outside its frame, by build number & 3
+    uint32_t grid_par = 0;            // the SbGridCtl block the next launch reads
     SbGridCtl grid_ctl0[2]{};         // the decision state a fresh upload starts from
-    size_t grid_heads = 0, grid_slots = 0; // entries of d_head, of each d_blk_max
+    size_t grid_heads = 0, grid_slots = 0; // entries of each d_head, of d_blk_max
+    bool grid_force = false;          // the next substep starts with a forced helper launch (upload, ghost refresh, hybrid, abort recovery)
+    uint32_t grid_classic_left = 0, grid_classic_chunk = 0; // substeps left in the classic stretch after an abort; its length (doubles per abort, decays when calm)
+    uint32_t grid_calm = 0;           // lagged substeps since the last abort
+    uint32_t grid_executed = 0;       // host mirror of SbGridCtl::executed: single substeps run since the upload
+    uint64_t grid_aborts = 0, grid_helper_launches = 0, grid_classic_substeps = 0; // statistics (sb_get_info)
     uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)
     // pinned staging of uploads and read-backs (sb_api.hip: stage_*): two chunks, filled / drained by several host threads while
     // the other one is on the wire (hipMemcpy from pageable memory stages through ONE thread: ~5 GB/s)
@@ -209,6 +213,8 @@ struct sb_engine {
 
 // sb_kernels.hip
 void sbk_launch_substep(sb_engine *e, bool write_aux);
+uint32_t sbk_grid_mode(const sb_engine *e); // SB_GRID_LAGGED / SB_GRID_CLASSIC: the schedule the next substep's launch will run
+void sbk_launch_grid_settle(sb_engine *e);   // the next substep's decision ahead of time, into e->d_grid_ctl[e->grid_par] (the host's look)
 void sbk_launch_delete(sb_engine *e);
 void sbk_launch_lists_min_d2(sb_engine *e); // e->d_grid_nonempty[0] = squared distance of the closest pair any neighbour list holds (float; hybrid look)
 void sbk_launch_halo_clear_ghost_flags(sb_engine *e);

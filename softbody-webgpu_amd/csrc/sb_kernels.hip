@@ -8,6 +8,7 @@
 //                   with LDS integer atomics and consumed in the same launch.
 // Both are HBM-bandwidth-bound (no MFMA: < 1 flop/byte).
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 #include "sb_engine.h"
@@ -51,10 +52,22 @@ template <int MODE>
 __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbParticleArrays w,
                                                         int2 *forces, uint32_t P,
                                                         const SbConsts c, SbParams prm,
-                                                        const uint32_t *__restrict__ pidx, SbGrid grid,
-                                                        uint32_t *blk_max)
+                                                        const uint32_t *__restrict__ pidx, SbGrid grid_all,
+                                                        SbGridJob job)
 {
     __shared__ float2 s_pos[SB_BLOCK];
+    __shared__ SbGridShared s_grid;
+    SbGrid grid = grid_all;
+    if (MODE == SB_COLLIDE_GRID) { // the decision (sb_physics.h SbGridCtl); this path runs the classic schedule only
+        const SbGridEarly early = sb_grid_begin(job.step);
+        sb_grid_stage(job.step, early, s_grid, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) sb_grid_decide(job.step, grid_all, s_grid, 1u, true);
+        __syncthreads();
+        if (s_grid.now.abort != 0u) return; // (uniform; nothing has been written)
+        if (blockIdx.x == 0 && threadIdx.x < SB_GRID_SLOTS) job.step.slots_zero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grid = sb_grid_view(grid_all, s_grid.now.cur, &s_grid.now.geo, s_grid.now.Cx, s_grid.now.Cy);
+    }
     uint32_t i = blockIdx.x * SB_BLOCK + threadIdx.x;
     bool active = i < P;
     SbParticle particle, self;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         }
     }
     if (MODE == SB_COLLIDE_GRID && active) {
-        sb_collide_slow(grid, SB_CTL_LOAD(&grid.ctl->rebuild) != 0u, prm, c.friction, elasticity_coeff, particle, self, i,
+        sb_collide_slow(grid, s_grid.now.fresh != 0u, prm, c.friction, elasticity_coeff, particle, self, i,
                         pidx, r.pos, r.vel);
     }
     float moved = 0.0f;
@@ -98,15 +111,14 @@ __global__ __launch_bounds__(SB_BLOCK) void k_particles(SbParticleArrays r, SbPa
         sb_particle_finish(prm, c, particle, f.x, f.y);
         if (MODE == SB_COLLIDE_GRID) {
             const float dx = particle.p.x - self.p.x, dy = particle.p.y - self.p.y;
-            moved = fmaxf(sb_abs(dx - SB_CTL_LOAD(&grid.ctl->cx)), sb_abs(dy - SB_CTL_LOAD(&grid.ctl->cy))) * 1.4142137f;
-            if (threadIdx.x == 0) sb_store_sample_displacement(blk_max, gridDim.x, dx, dy);
+            moved = fmaxf(sb_abs(dx - s_grid.now.cx), sb_abs(dy - s_grid.now.cy)) * 1.4142137f;
+            if (threadIdx.x == 0) sb_store_sample_displacement(job.step.slots_out, dx, dy);
         }
+        w.pos[i] = particle.p;
+        w.vel[i] = particle.v;
+        w.acc[i] = particle.a;
     }
-    if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
-    if (!active) return;
-    w.pos[i] = particle.p;
-    w.vel[i] = particle.v;
-    w.acc[i] = particle.a;
+    if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(job.step.slots_out, moved);
 }
 
 
@@ -136,16 +148,21 @@ SB_DEV uint32_t sb_tile_of_block(uint32_t b, uint32_t n)
         const uint32_t *__restrict__ tile_b0, const uint32_t *__restrict__ tile_h0,                                 \
         const uint32_t *__restrict__ halo_idx, uint32_t ntiles, uint32_t cap_all, uint32_t cap_own, uint32_t lbits, \
         const float *__restrict__ mat_tab, uint32_t nmat, const SbConsts c, SbParams prm, uint32_t *broken,         \
-        const uint32_t *__restrict__ pidx, SbGrid grid, uint32_t *blk_max, const uint32_t *__restrict__ acc_flag_r, \
+        const uint32_t *__restrict__ pidx, SbGrid grid_all, SbGridJob job, const uint32_t *__restrict__ acc_flag_r, \
         uint32_t *acc_flag_w
 #define SB_TILED_ARGS                                                                                               \
     r, w, b, tile_p0, tile_b0, tile_h0, halo_idx, ntiles, cap_all, cap_own, lbits, mat_tab, nmat, c, prm, broken,   \
-        pidx, grid, blk_max, acc_flag_r, acc_flag_w
+        pidx, grid_all, job, acc_flag_r, acc_flag_w
 
 template <int MODE, int MAT, bool AUX>
 __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
+    __shared__ SbGridShared s_grid;
+    SbGridEarly early;
+#ifdef SB_STAMPS
+    const uint64_t sb_t_start = wall_clock64();
+#endif
     float2 *s_pos = (float2 *)sb_lds;
     int *s_f = (int *)(s_pos + cap_all);
     float *s_mat = (float *)(s_f + 2 * cap_all); // accumulators exist for halo slots too: their sums are never read
@@ -179,6 +196,11 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
             pa[u] = acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f);
         }
     }
+    // SB_COLLIDE_GRID: last substep's displacement slots and the control block, requested together with the own particles (cold
+    // lines, a full trip to memory like them; the wait counter retires in order, so requested any earlier they would stand in
+    // front of the acceleration flags and halo indices, which come out of the L2): they turn into this substep's decision
+    // behind the first barrier (sb_physics.h SbGridCtl)
+    if (MODE == SB_COLLIDE_GRID) early = sb_grid_begin(job.step);
     float2 hp = make_float2(0.f, 0.f);
     if (has_halo) hp = r.pos[hidx];
 #pragma unroll
@@ -212,17 +234,59 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
     uint32_t ncand[SB_UNROLL];
     bool fresh = false;
     float drift_x = 0.0f, drift_y = 0.0f; // SbGridCtl: the common displacement this substep is measured against
+    float drift_Cx = 0.0f, drift_Cy = 0.0f; // ... and the drift accumulated since the hash in use was built
     if (MODE == SB_COLLIDE_GRID) {
-        fresh = SB_CTL_LOAD(&grid.ctl->rebuild) != 0u;
-        drift_x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_CTL_LOAD(&grid.ctl->cx)))); // uniform: SGPRs
-        drift_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(SB_CTL_LOAD(&grid.ctl->cy))));
 #pragma unroll
-        for (int u = 0; u < SB_UNROLL; u++) {
+        for (int u = 0; u < SB_UNROLL; u++) { // (requested whatever the decision will be: on a list-making substep the main pass is skipped)
             const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
-            ncand[u] = (i < n_own && !fresh) ? grid.nl_count[p0 + i] : 0u;
+            ncand[u] = i < n_own ? grid_all.nl_count[p0 + i] : 0u;
         }
+        SB_STAMP(job.step, 0);
+        sb_grid_stage(job.step, early, s_grid, 1u);
+        SB_STAMP(job.step, 1);
     }
     __syncthreads();
+    SbGrid grid = grid_all;
+    bool pushing = false;
+    if (MODE == SB_COLLIDE_GRID) {
+        SB_STAMP(job.step, 2);
+        // what every thread needs of the decision: lane 0 of wave 0 has left it in LDS (uniform: broadcast reads).  The whole
+        // block is thread 0's business -- in workgroup 0, which publishes it for the next launch, and on the rare substeps that
+        // make lists or push the next hash, where every workgroup reads it (behind a barrier)
+        const SbGridFlags gf = s_grid.hot.f;
+        const bool whole = blockIdx.x == 0 || __builtin_amdgcn_readfirstlane(gf.fresh | gf.pushing | gf.abort) != 0u;
+        if (whole && tid == 0) sb_grid_decide(job.step, grid_all, s_grid, 1u, true);
+        drift_x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_grid.hot.cx))); // uniform: SGPRs
+        drift_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_grid.hot.cy)));
+        drift_Cx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_grid.hot.Cx)));
+        drift_Cy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_grid.hot.Cy)));
+        SB_STAMP(job.step, 3);
+        if (__builtin_amdgcn_readfirstlane(gf.abort) != 0u) return; // (nothing has been written; workgroup 0 has told the launches behind)
+        if (blockIdx.x == 0 && tid < SB_GRID_SLOTS) job.step.slots_zero[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        fresh = __builtin_amdgcn_readfirstlane(gf.fresh) != 0u;
+        pushing = __builtin_amdgcn_readfirstlane(gf.pushing) != 0u;
+        SB_STAMP(job.step, 4);
+    }
+
+    // Lagged schedule (SbGridCtl): the tail of the substep before this one ordered the next hash.  Every workgroup pushes its own
+    // particles -- the READ state, which sits in LDS -- into the OTHER hash buffer; the lists in use serve this substep, the
+    // next one makes its lists from what is pushed here.  Nobody reads these stores before the launch has retired.
+    if (MODE == SB_COLLIDE_GRID && pushing) {
+        __syncthreads(); // (thread 0 has chosen the geometry)
+        const SbGridGeom pg = sb_grid_geom_load(&s_grid.now.pgeo);
+        const uint32_t buf = __builtin_amdgcn_readfirstlane(s_grid.now.cur) ^ 1u;
+        uint32_t n_out = 0u;
+#pragma unroll 1
+        for (uint32_t i = tid; i < n_own; i += SB_TILE_BLOCK) {
+            const float2 p = s_pos[i];
+            uint32_t cell;
+            bool o = false;
+            const unsigned long long old = sb_grid_push_begin(job.build, buf, pg, p0 + i, p, &cell, &o);
+            n_out += o ? 1u : 0u;
+            sb_grid_push_end(job.build, buf, pg, p0 + i, p, job.pslot[p0 + i], cell, old);
+        }
+        sb_grid_count_outside(&job.build.outside[pg.gen & 3u], n_out);
+    }
 
     // Beam phase.  The slice is walked in batches of SB_UNROLL x SB_TILE_BLOCK copies: all global loads of a
     // batch are issued back to back (and the next batch's before this one is evaluated), so a wave
@@ -315,6 +379,13 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
     }
     __syncthreads();
 
+    if (MODE == SB_COLLIDE_GRID) {
+        SB_STAMP(job.step, 5);
+        // a substep that makes its lists: from the block thread 0 decided (behind the barrier that ends the beam phase);
+        // otherwise the hash, its geometry and its age are those of the block this launch read
+        if (fresh) grid = sb_grid_view(grid_all, s_grid.now.cur, &s_grid.now.geo, s_grid.now.Cx, s_grid.now.Cy);
+        else grid = sb_grid_view(grid_all, s_grid.prev.cur, &s_grid.prev.geo, drift_Cx, drift_Cy);
+    }
     // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
     bool any_acc = false;
     float moved = 0.0f;
@@ -343,7 +414,7 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
         if (MODE == SB_COLLIDE_GRID) {
             const float dx = particle.p.x - p_old.x, dy = particle.p.y - p_old.y;
             moved = fmaxf(moved, fmaxf(sb_abs(dx - drift_x), sb_abs(dy - drift_y)) * 1.4142137f);
-            if (i == 0u) sb_store_sample_displacement(blk_max, ntiles, dx, dy); // i == 0 is thread 0's first particle
+            if (i == 0u) sb_store_sample_displacement(job.step.slots_out, dx, dy); // i == 0 is thread 0's first particle
         }
         w.pos[g] = particle.p;
         w.vel[g] = particle.v;
@@ -379,10 +450,11 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
         }
     }
 #if !(SB_ABLATE & 128) // diagnostic build: no displacement tracking
-    if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(blk_max, moved);
+    if (MODE == SB_COLLIDE_GRID) sb_store_block_displacement(job.step.slots_out, moved);
 #endif
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
     if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
+    if (MODE == SB_COLLIDE_GRID) SB_STAMP(job.step, 6);
 }
 
 // The two entry points.  With the collision walk compiled in, the body wants 71 VGPRs: 7 waves per SIMD, i.e.
@@ -403,130 +475,62 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     sb_substep_tiled<SB_COLLIDE_GRID, MAT, AUX>(SB_TILED_ARGS);
 }
 
-// ---------------------------------------------------------------- spatial hash build
-// ONE launch per substep (k_grid_maintain) in front of the particle kernel.  Every workgroup reduces the
-// previous substep's per-workgroup displacement maxima and takes the same decision (SbGridCtl,
-// sb_physics.h); on most substeps that is all and the kernel retires.  When the hash must be rebuilt the
-// SAME launch does it in ONE pass with no device-wide barrier: every particle pushes itself on the front of its
-// cell's linked list with one 64-bit exchange (the head word carries the number of the build that wrote it, so the
-// cells of older builds read as empty and nothing is ever cleared), and writes its own record.  (Round 1 counted,
-// scanned and scattered into cell-sorted records: three device-wide barriers, a scan over every cell and two passes
-// over the particles, 70-90 us per build; tools/grid_phases.py.)
-// Decision state and the displacement slots are double buffered by substep parity: this launch reads
-// ctl[par] / blk_max[par] and publishes ctl[par^1]; the particle kernel that follows fills blk_max[par^1].
-#define SB_MAINTAIN_BLOCKS 128u // (r03, pile / soup: 32 -> 38.9 / 57.4, 64 -> 37.7 / 53.9, 128 -> 37.3 / 52.8 us per substep; r02: 64 -> 41.5, 128 -> 42.2, 256..1024 -> 44.7-45.0;
-                              // the launch runs on every substep and only rebuilds on one in 4-14)
+// ---------------------------------------------------------------- spatial hash build (the helper launch)
+// r04: the per-substep helper launch of rounds 1-3 (k_grid_maintain: reduce the displacement slots, decide, rebuild when the
+// bound demands it) is gone from the steady state.  The decision is taken by the last workgroup of every particle kernel
+// (sb_grid_tail, sb_physics.h); in the lagged schedule the particle kernels also push the hash themselves, one substep ahead.
+// What is left is this helper, launched by the host
+//   * forced: when the HOST knows the lists are worthless (first substep after an upload, ghost refresh, the hybrid's fresh
+//     start, recovery from an abort): builds from the current state and publishes the state the next substep reads;
+//   * unforced, in front of every substep of a CLASSIC stretch (violent scenes, the atomic path): builds when the tail of the
+//     substep before ordered it (`need_build`), else returns at once.
+// ONE pass, no device-wide barrier, no residency requirement (sb_grid_push_begin / _end).  (Round 1 counted, scanned and
+// scattered into cell-sorted records: three device-wide barriers, 70-90 us per build; tools/grid_phases.py.)
+#define SB_BUILD_BLOCKS 128u // (r03, pile / soup: 32 -> 38.9 / 57.4, 64 -> 37.7 / 53.9, 128 -> 37.3 / 52.8 us per substep)
 #ifndef SB_MT
-#define SB_MT 1024u // threads per workgroup of k_grid_maintain
+#define SB_MT 1024u // threads per workgroup of k_grid_build
 #endif
 
-struct SbGridBuild {
-    unsigned long long *head;
-    uint32_t *cell_of;
-    float4 *rec;
-    uint32_t *done;    // workgroups of the build in progress that have finished (zero between builds)
-    uint32_t *err;     // (words 4.. : block 0's phase stamps, tools/grid_phases.py)
-    uint32_t *outside; // particles the build in progress found outside its frame (zero between builds)
-};
-
-__global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const uint32_t *blk_max, uint32_t nblk,
-                                                            uint32_t par, const float2 *__restrict__ pos,
-                                                            const uint32_t *__restrict__ pslot, uint32_t P, SbGrid g,
-                                                            SbGridBuild w)
+__global__ __launch_bounds__(SB_MT) void k_grid_build(SbGridStep t, uint32_t force, const float2 *__restrict__ pos,
+                                                      const uint32_t *__restrict__ pslot, SbGrid g, SbGridBuild w)
 {
-    __shared__ float s_wave_max[SB_MT / 64], s_wave_sx[SB_MT / 64], s_wave_sy[SB_MT / 64];
+    __shared__ SbGridShared s_grid;
     const uint32_t tid = threadIdx.x;
-    // ---- decision, identical in every workgroup (everything read here was written by earlier launches)
-    const SbGridCtl *cin = ctl + par;
-    const float skin = SB_CTL_LOAD(&cin->skin), accum_in = SB_CTL_LOAD(&cin->accum); // in flight with the slots
-    const uint32_t builds = SB_CTL_LOAD(&cin->builds), force = SB_CTL_LOAD(&cin->force);
-    const float c_used_x = SB_CTL_LOAD(&cin->cx), c_used_y = SB_CTL_LOAD(&cin->cy); // what the last substep used
-    const float C_in_x = SB_CTL_LOAD(&cin->Cx), C_in_y = SB_CTL_LOAD(&cin->Cy);
-    const SbGridGeom geom_in = sb_grid_geom_load(cin);
-    const uint32_t since = SB_CTL_LOAD(&cin->since);
-    const float skin_min = SB_CTL_LOAD(&cin->skin_min), skin_max = SB_CTL_LOAD(&cin->skin_max);
-    float m = 0.0f, sx = 0.0f, sy = 0.0f;
-    for (uint32_t i = tid; i < nblk; i += SB_MT) { // per-lane addresses: vector loads
-        m = fmaxf(m, __uint_as_float(blk_max[i]));
-        sx += __uint_as_float(blk_max[nblk + i]);
-        sy += __uint_as_float(blk_max[2u * nblk + i]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmaxf(m, __shfl_xor(m, off, 64));
-        sx += __shfl_xor(sx, off, 64);
-        sy += __shfl_xor(sy, off, 64);
-    }
-    if ((tid & 63u) == 0u) {
-        s_wave_max[tid >> 6] = m;
-        s_wave_sx[tid >> 6] = sx;
-        s_wave_sy[tid >> 6] = sy;
-    }
+    const SbGridEarly early = sb_grid_begin(t);
+    sb_grid_stage(t, early, s_grid, 1u);
     __syncthreads();
-    float step = 0.0f, tot_x = 0.0f, tot_y = 0.0f;
-    for (int k = 0; k < SB_MT / 64; k++) {
-        step = fmaxf(step, s_wave_max[k]);
-        tot_x += s_wave_sx[k];
-        tot_y += s_wave_sy[k];
-    }
-    const float accum = accum_in + step; // bound for the READ state of this substep
-    const bool rebuild = force != 0u || !(accum <= skin); // NaN-safe
-    // the skin of the hash about to be built follows how long the last one lasted (SbGridCtl)
-    float skin_new = skin;
-    if (rebuild && force == 0u) {
-        if (since <= 3u) {
-            // short-lived hash: a doubled skin must promise at least two substeps at the rate the bound has been
-            // growing, else the scene is simply too violent for any hash to last and lean cells are the cheapest
-            const float rate = accum / (float)since, wider = fminf(skin * 2.0f, skin_max);
-            if (wider >= 2.0f * rate) skin_new = wider;
-            else if (!(skin >= 2.0f * rate)) skin_new = skin_min;
-        } else if (since >= 64u) {
-            skin_new = fmaxf(skin * 0.5f, skin_min);
+    if (tid == 0) {
+        if (force) { // the host knows the lists are worthless: a hash of the current state, whatever the bound says.  Every
+            // workgroup computes the same block from the same words; block 0 publishes it, `settled`: the substep that
+            // follows adopts it as it stands
+            const SbGridCtl &E = s_grid.prev;
+            SbGridCtl &N = s_grid.now; // (a copy of E so far: sb_grid_stage)
+            N.fresh = 1u;
+            N.need_build = N.pushing = N.abort = 0u;
+            N.settled = 1u;
+            N.cur = E.cur ^ 1u;
+            N.builds = E.builds + 1u;
+            N.since = 1u;
+            N.accum = N.Cx = N.Cy = 0.0f;
+            N.geo = sb_grid_geom_for(g, E.geo.skin, (E.geo.wide != 0u || E.wide_next != 0u) ? 1u : 0u);
+            N.geo.gen = N.builds;
+            if (blockIdx.x == 0u) {
+                const uint32_t *src = (const uint32_t *)&s_grid.now;
+                uint32_t *dst = (uint32_t *)(t.ctl + (t.par ^ 1u));
+                for (uint32_t k = 0; k < sizeof(SbGridCtl) / 4u; k++) SB_AGENT_STORE(&dst[k], src[k]);
+                SB_AGENT_STORE(&t.outside[(N.geo.gen + 1u) & 3u], 0u);
+            }
+        } else {
+            sb_grid_decide(t, g, s_grid, 1u, false); // what the substep behind this launch will decide
         }
     }
-    // the frame: tight until the build before this one found more than 1/64 of the particles outside it (that build's
-    // block 0 published the verdict in wide_next; every workgroup of this launch reads the same word)
-    const uint32_t wide_next_in = SB_CTL_LOAD(&cin->wide_next);
-    const uint32_t wide = (geom_in.wide != 0u || wide_next_in != 0u) ? 1u : 0u;
-    const SbGridGeom geo = rebuild ? sb_grid_geom_for(g, skin_new, wide) : geom_in;
-    // the common displacement the coming substep is measured against: the mean of the one just done
-    float mean_x = tot_x / (float)nblk, mean_y = tot_y / (float)nblk; // one sample particle per workgroup
-    if (!(sb_abs(mean_x) < 1.0e30f) || !(sb_abs(mean_y) < 1.0e30f)) mean_x = mean_y = 0.0f;
-    if (blockIdx.x == 0 && tid == 0) {
-        SbGridCtl *cout = ctl + (par ^ 1u);
-        SB_AGENT_STORE(&cout->rebuild, rebuild ? 1u : 0u);
-        SB_AGENT_STORE(&cout->force, 0u);
-        SB_AGENT_STORE(&cout->accum, rebuild ? 0.0f : accum);
-        SB_AGENT_STORE(&cout->skin, geo.skin);
-        SB_AGENT_STORE(&cout->cell, geo.cell);
-        SB_AGENT_STORE(&cout->reach2, geo.reach2);
-        SB_AGENT_STORE(&cout->nx, geo.nx);
-        SB_AGENT_STORE(&cout->ny, geo.ny);
-        SB_AGENT_STORE(&cout->x0, geo.x0);
-        SB_AGENT_STORE(&cout->y0, geo.y0);
-        SB_AGENT_STORE(&cout->wide, geo.wide);
-        if (!rebuild) SB_AGENT_STORE(&cout->wide_next, wide_next_in); // (a build publishes its own verdict after its count phase)
-        SB_AGENT_STORE(&cout->since, rebuild ? 1u : since + 1u);
-        SB_AGENT_STORE(&cout->skin_min, skin_min);
-        SB_AGENT_STORE(&cout->skin_max, skin_max);
-        SB_AGENT_STORE(&cout->builds, builds + (rebuild ? 1u : 0u));
-        SB_AGENT_STORE(&cout->cx, mean_x);
-        SB_AGENT_STORE(&cout->cy, mean_y);
-        SB_AGENT_STORE(&cout->Cx, rebuild ? 0.0f : C_in_x + c_used_x);
-        SB_AGENT_STORE(&cout->Cy, rebuild ? 0.0f : C_in_y + c_used_y);
-    }
-    if (!rebuild) return;
-#define SB_GRID_STAMP(k)                                                                                        \
-    do {                                                                                                        \
-        if (blockIdx.x == 0 && tid == 0) w.err[4 + (k)] = (uint32_t)(wall_clock64() - t_start); /* 10 ns ticks */ \
-    } while (0)
-    const uint64_t t_start = wall_clock64();
-
-    const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
-    const unsigned long long gen = (unsigned long long)(builds + 1u) << 32; // what the particle kernel reads as SbGridGeom::gen
-    // ---- every particle: its cell, itself pushed on the front of that cell's list (one returning exchange; the order
-    // inside a list is arbitrary, which is fine: contacts are re-ordered by slot), its record
+    __syncthreads();
+    if (!force && (s_grid.now.need_build == 0u || s_grid.now.abort != 0u)) return;
+    const SbGridGeom geo = sb_grid_geom_load(&s_grid.now.geo);
+    const uint32_t buf = __builtin_amdgcn_readfirstlane(s_grid.now.cur), P = t.P;
+    // ---- every particle: its cell, itself pushed on the front of that cell's list, its record
     // (four particles per thread and round, so that four returning atomics are in flight per lane)
+    const uint32_t nthreads = gridDim.x * SB_MT, gtid = blockIdx.x * SB_MT + tid;
     uint32_t n_out = 0u;
     for (uint32_t i0 = gtid; i0 < P; i0 += 4u * nthreads) {
         uint32_t c[4], slot[4];
@@ -540,52 +544,31 @@ __global__ __launch_bounds__(SB_MT) void k_grid_maintain(SbGridCtl *ctl, const u
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const bool have = i0 + (uint32_t)u * nthreads < P;
-            bool o = false;
-            c[u] = sb_grid_coord_flag(p[u].y, geo.y0, geo.cell, geo.ny, &o) * geo.nx +
-                   sb_grid_coord_flag(p[u].x, geo.x0, geo.cell, geo.nx, &o);
-            n_out += (have && o) ? 1u : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)u * nthreads;
-            if (i < P) old[u] = atomicExch(&w.head[c[u]], gen | i);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
             const uint32_t i = i0 + (uint32_t)u * nthreads;
             if (i < P) {
-                const uint32_t next = (old[u] >> 32) == (gen >> 32) ? (uint32_t)old[u] : SB_CHAIN_END;
-                w.cell_of[i] = c[u];
-                w.rec[i] = make_float4(p[u].x, p[u].y, __uint_as_float(slot[u]), __uint_as_float(next));
+                bool o = false;
+                old[u] = sb_grid_push_begin(w, buf, geo, i, p[u], &c[u], &o);
+                n_out += o ? 1u : 0u;
             }
         }
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
-    // one per wave, and only when somebody left the frame; the RETURNING form: the wave has the old value back only once the
-    // add has been performed at the device's coherence point, which orders it before the workgroup's ticket below
-    if (n_out && (tid & 63u) == 0u) {
-        uint32_t seen = __hip_atomic_fetch_add(w.outside, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(seen));
-    }
-    SB_GRID_STAMP(0);
-    // ---- the workgroup that finishes last reads the total, publishes the verdict for the next build and re-zeroes both
-    // counters (nobody touches them again before the next build, a later launch).  The ticket is a relaxed agent-scope
-    // read-modify-write: the counts it must follow are agent-scope atomics that have already returned, and everything else
-    // this kernel writes is read by LATER launches only.  (A release here writes the whole L2 back: ~10 us per build.)
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(w.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1u) {
-            const uint32_t total = __hip_atomic_load(w.outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            SB_AGENT_STORE(&ctl[par ^ 1u].wide_next, (wide != 0u || total > P / 64u) ? 1u : 0u);
-            SB_AGENT_STORE(w.outside, 0u);
-            SB_AGENT_STORE(w.done, 0u);
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthreads;
+            if (i < P) sb_grid_push_end(w, buf, geo, i, p[u], slot[u], c[u], old[u]);
         }
     }
-    SB_GRID_STAMP(1);
-#undef SB_GRID_STAMP
+    sb_grid_count_outside(&w.outside[geo.gen & 3u], n_out);
+}
+
+// The decision ahead of time, for the host's look between launches (sb_api.hip hybrid_substeps): what the next substep would
+// decide from the displacement slots of the last one, published `settled` -- the substep that follows adopts it as it stands.
+__global__ __launch_bounds__(SB_GRID_SLOTS) void k_grid_settle(SbGridStep t, SbGrid g)
+{
+    __shared__ SbGridShared s_grid;
+    const SbGridEarly early = sb_grid_begin(t);
+    sb_grid_stage(t, early, s_grid, 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) sb_grid_decide(t, g, s_grid, 0u, true);
 }
 
 // ---------------------------------------------------------------- delete pass (compute.wgsl:205-246)
@@ -649,14 +632,14 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_pack(SbParticleArrays c, SbBe
 // What a refresh may do to the per-tile promises: a ghost particle that arrives with an acceleration breaks
 // "every acceleration of this tile is zero", a ghost beam whose target arrives changed (its owner's copy yielded) breaks "no beam
 // of this tile has ever yielded" -- for THAT tile (found by bisection of the tile tables; both events are rare), not for all of
-// them as three memsets per refresh used to say.  `flags.force`: the spatial hash rebins after a refresh (ghosts jumped).
+// them as three memsets per refresh used to say.  (The spatial hash rebins after a refresh -- ghosts jumped: the host's business,
+// sbk_launch_halo_unpack.)
 struct SbHaloFlags {
     uint32_t *acc_flag;          // the current particle buffer's flags (nullptr: no tiles)
     const uint32_t *tile_p0;     // [ntiles + 1]
     uint32_t ntiles;
     uint32_t *plastic0, *plastic1; // blocked layout only (else nullptr), with
     const uint32_t *tile_b0;     // its beams per tile
-    uint32_t *force0, *force1;   // SbGridCtl::force of both parities (nullptr without a hash)
 };
 SB_DEV uint32_t sb_range_of(const uint32_t *__restrict__ first, uint32_t n, uint32_t i) // largest t < n with first[t] <= i
 {
@@ -679,10 +662,6 @@ __global__ __launch_bounds__(SB_BLOCK) void k_halo_unpack(SbParticleArrays c, Sb
                                                           const uint32_t *__restrict__ dead_gen, SbHaloFlags flags)
 {
     uint32_t k = blockIdx.x * SB_BLOCK + threadIdx.x;
-    if (k == 0u && flags.force0) {
-        SB_AGENT_STORE(flags.force0, 1u);
-        SB_AGENT_STORE(flags.force1, 1u);
-    }
     if (k < np) {
         uint32_t i = plist[k];
         const float2 *in = (const float2 *)(src + poff[k]);
@@ -793,33 +772,82 @@ __global__ __launch_bounds__(64) void k_peer_signal_wait(SbPeerSignal s)
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// the schedule of the next substep's hash work (SbGridCtl): lagged unless the engine is inside a classic stretch, runs the
+// atomic path (its particle kernel does not push), or SB_GRID_MODE says otherwise (A/B runs, the fallback's tests)
+uint32_t sbk_grid_mode(const sb_engine *e)
+{
+    static const int forced = [] {
+        const char *v = getenv("SB_GRID_MODE");
+        return !v ? -1 : (!strcmp(v, "classic") ? (int)SB_GRID_CLASSIC : (!strcmp(v, "lagged") ? (int)SB_GRID_LAGGED : -1));
+    }();
+    if (e->path != SB_PATH_TILED) return SB_GRID_CLASSIC;
+    if (forced >= 0) return (uint32_t)forced;
+    return e->grid_classic_left ? SB_GRID_CLASSIC : SB_GRID_LAGGED;
+}
+
+// what a launch that decides needs: the control blocks and the displacement slots by the number of the substep it is (or is in front of)
+static SbGridStep sbk_grid_step(const sb_engine *e, uint32_t sched)
+{
+    const uint32_t nblk = e->path == SB_PATH_TILED ? e->ntiles : cdiv(e->P, SB_BLOCK), k = e->grid_executed; // substeps run so far
+    float4 *slots = (float4 *)e->d_blk_max;
+    SbGridStep st{e->d_grid_ctl, e->grid_par, sched, slots + (size_t)(k % 3u) * SB_GRID_SLOTS, slots + (size_t)((k + 1u) % 3u) * SB_GRID_SLOTS,
+                  slots + (size_t)((k + 2u) % 3u) * SB_GRID_SLOTS, 1.0f / (float)std::min<uint32_t>(std::max(nblk, 1u), SB_GRID_SLOTS), e->d_grid_outside, e->P};
+#ifdef SB_STAMPS
+    st.stamps = e->dev_err + 4; // (pinned host memory, mapped: sb_get_info "grid_stamp_<k>")
+#endif
+    return st;
+}
+static SbGridBuild sbk_grid_arrays(const sb_engine *e)
+{
+    return SbGridBuild{{e->d_head[0], e->d_head[1]}, {e->d_cell_of[0], e->d_cell_of[1]}, {e->d_rec[0], e->d_rec[1]}, e->d_grid_outside};
+}
+static uint32_t sbk_build_blocks(const sb_engine *e)
+{
+    static const uint32_t max_blocks = [] { // tuning knob (no residency requirement: the build has no device-wide barrier)
+        const char *v = getenv("SB_MAINTAIN_BLOCKS");
+        const long n = v ? atol(v) : 0;
+        return n >= 1 && n <= 4096 ? (uint32_t)n : SB_BUILD_BLOCKS;
+    }();
+    return std::min(std::max(cdiv(e->P, SB_MT * 4u), 1u), max_blocks);
+}
+
+// the host's look between launches: the decision ahead of time (e->d_grid_ctl[e->grid_par] then holds it, `settled`)
+void sbk_launch_grid_settle(sb_engine *e)
+{
+    k_grid_settle<<<1, SB_GRID_SLOTS, 0, e->stream>>>(sbk_grid_step(e, sbk_grid_mode(e)), e->grid);
+    e->grid_par ^= 1u;
+}
+
 void sbk_launch_substep(sb_engine *e, bool write_aux)
 {
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
     const uint32_t mode = e->opt.collision_mode;
+    SbGridJob job{};
     if (mode == SB_COLLIDE_GRID && e->P) {
-        // decide, and when the displacement bound demands it rebuild the spatial hash from the READ state
-        const uint32_t nblk = e->path == SB_PATH_TILED ? e->ntiles : cdiv(e->P, SB_BLOCK);
-        static const uint32_t max_blocks = [] { // tuning knob (no residency requirement: the build has no device-wide barrier)
-            const char *v = getenv("SB_MAINTAIN_BLOCKS");
-            const long n = v ? atol(v) : 0;
-            return n >= 1 && n <= 4096 ? (uint32_t)n : SB_MAINTAIN_BLOCKS;
-        }();
-        const uint32_t blocks = std::min(std::max(cdiv(e->P, SB_MT * 4u), 1u), max_blocks);
-        SbGridBuild gb{e->d_head, e->d_cell_of, e->d_rec, e->d_grid_done, e->dev_err, e->d_grid_outside};
-        k_grid_maintain<<<blocks, SB_MT, 0, e->stream>>>(e->d_grid_ctl, e->d_blk_max[e->grid_par], nblk, e->grid_par,
-                                                            r.pos, e->d_pslot, e->P, e->grid, gb);
-        e->grid_par ^= 1u;
-        e->grid.ctl = &e->d_grid_ctl[e->grid_par]; // what that launch just published
+        const uint32_t sched = sbk_grid_mode(e);
+        const SbGridBuild gb = sbk_grid_arrays(e);
+        // the helper: forced when the host knows the lists are worthless; unforced in front of every substep of the classic
+        // schedule (it takes the substep's decision itself and builds when that says so); not at all in the lagged steady state
+        if (e->grid_force) {
+            k_grid_build<<<sbk_build_blocks(e), SB_MT, 0, e->stream>>>(sbk_grid_step(e, sched), 1u, r.pos, e->d_pslot, e->grid, gb);
+            e->grid_par ^= 1u; // (it published the state the substep adopts)
+            e->grid_force = false;
+            e->grid_helper_launches++;
+        } else if (sched == SB_GRID_CLASSIC) {
+            k_grid_build<<<sbk_build_blocks(e), SB_MT, 0, e->stream>>>(sbk_grid_step(e, sched), 0u, r.pos, e->d_pslot, e->grid, gb);
+            e->grid_helper_launches++;
+        }
+        job.step = sbk_grid_step(e, sched);
+        job.build = gb;
+        job.pslot = e->d_pslot;
     }
-    uint32_t *blk_out = e->d_blk_max[e->grid_par]; // the slots the NEXT maintain launch reads
     if (e->path == SB_PATH_ATOMIC) {
         if (e->nbeam)
             k_beams_atomic<<<cdiv(e->nbeam, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->beams, e->nbeam, r.pos,
                                                                                e->d_forces, e->d_broken);
         if (e->P) {
             dim3 g(cdiv(e->P, SB_BLOCK));
-#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, blk_out)
+#define SB_LAUNCH_P(M) k_particles<M><<<g, SB_BLOCK, 0, e->stream>>>(r, w, e->d_forces, e->P, e->consts, e->prm, e->d_pidx, e->grid, job)
             if (mode == SB_COLLIDE_ALLPAIRS) SB_LAUNCH_P(SB_COLLIDE_ALLPAIRS);
             else if (mode == SB_COLLIDE_GRID) SB_LAUNCH_P(SB_COLLIDE_GRID);
             else SB_LAUNCH_P(SB_COLLIDE_OFF);
@@ -829,7 +857,7 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #define SB_LAUNCH_T(K, T, A) K<T, A><<<e->ntiles, SB_TILE_BLOCK, e->lds_bytes, e->stream>>>(                            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
         e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
-        blk_out, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
+        job, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])
 #define SB_LAUNCH_TA(K, T) do { if (write_aux) SB_LAUNCH_T(K, T, true); else SB_LAUNCH_T(K, T, false); } while (0)
 #define SB_LAUNCH_TM(K) do { if (e->mat_mode == 2) SB_LAUNCH_TA(K, 2); else if (e->mat_mode == 1) SB_LAUNCH_TA(K, 1); else SB_LAUNCH_TA(K, 0); } while (0)
         if (mode == SB_COLLIDE_GRID) SB_LAUNCH_TM(k_substep_tiled_grid);
@@ -837,6 +865,10 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #undef SB_LAUNCH_TM
 #undef SB_LAUNCH_TA
 #undef SB_LAUNCH_T
+    }
+    if (mode == SB_COLLIDE_GRID && e->P) {
+        e->grid_par ^= 1u;   // (workgroup 0 of that launch publishes the other block)
+        e->grid_executed++;  // (an abort takes the count back: sb_api.hip grid_substeps)
     }
     e->cur ^= 1;
     e->substeps_done++;
@@ -928,10 +960,7 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src)
             flags.tile_b0 = e->bk.d_tile_b0;
         }
     }
-    if (e->d_grid_ctl) { // ghosts jumped: rebin (both parities: whichever the next maintain launch reads)
-        flags.force0 = &e->d_grid_ctl[0].force;
-        flags.force1 = &e->d_grid_ctl[1].force;
-    }
+    if (e->d_grid_ctl) e->grid_force = true; // ghosts jumped: the next substep starts with a forced build
     k_halo_unpack<<<cdiv(n, SB_BLOCK), SB_BLOCK, 0, e->stream>>>(e->part[e->cur], e->beams, e->d_ghost_p, e->d_ghost_p_off,
                                                                 e->n_ghost_p, e->d_ghost_b, e->d_ghost_b_off,
                                                                 e->n_ghost_b_copies, src, e->d_broken, e->d_dead_gen, flags);

@@ -434,6 +434,12 @@ struct SbGrid {
                                     // build number reads as "empty", so no cell is ever cleared
     const float4 *rec;          // per particle (record index == internal index): {x, y AT BUILD TIME, bits(slot), bits(next record)}
     const uint32_t *cell_of;    // per particle: its cell at the last build
+    // The hash is DOUBLE BUFFERED (r04): the three arrays above are buffer 0, these are buffer 1; SbGridCtl::cur says which one
+    // the neighbour lists in use came from.  A substep that pushes the next hash (SbGridCtl::pushing) writes the other buffer
+    // while particles with overflowed lists still scan the cells of the current one.
+    const unsigned long long *head1;
+    const float4 *rec1;
+    const uint32_t *cell_of1;
     float x0, y0, width, height; // the TIGHT frame: the uploaded bounding box plus a margin
     float two_r, cell_min;      // cells are never smaller than cell_min (what the arrays were sized for)
     uint32_t nx_cap, ny_cap;
@@ -447,7 +453,10 @@ struct SbGrid {
     uint32_t *nl_count;         // entries, or SB_NL_OVERFLOW: more than SB_NL_CAP, scan the cells instead
     uint32_t *nl;
     uint32_t nl_stride;
-    const struct SbGridCtl *ctl; // what the k_grid_maintain launch just before this kernel published
+    // filled in by the kernel itself once it has decided (sb_grid_view): the geometry of the hash the lists in use came from
+    // (a generic pointer into LDS) and the drift C accumulated since that hash was built
+    const struct SbGridGeom *geo;
+    float Cx, Cy;
 };
 #define SB_NL_CAP 16u
 #ifndef SB_NL_SEL
@@ -466,37 +475,58 @@ struct SbGrid {
 // build-time position, carried along by C, is farther than 2r + skin from the querying particle's
 // current position cannot be in contact: candidates are found in the stale cells, pre-filtered on
 // their drifted stale positions and tested exactly at their CURRENT positions.
-struct SbGridCtl {
-    uint32_t rebuild; // 1: the k_grid_maintain launch that wrote this rebuilt the hash (the particle kernel
-                      //    that follows makes the neighbour lists)
-    uint32_t force;   // set by the host (upload, halo unpack): rebuild unconditionally
-    float accum;      // D for the READ state of the coming substep
-    float skin;
-    uint32_t builds;  // statistics
-    float cx, cy;     // c for the coming substep
-    float Cx, Cy;     // C for the READ state of the coming substep
-    // geometry of the current hash.  The skin ADAPTS at every build: when the last hash lasted 3 substeps or less
-    // it doubles (up to skin_max) provided that promises two substeps at the rate the bound has been growing --
-    // if not even that, the scene is too violent for any hash to last and the skin drops back to skin_min; when
-    // a hash lasted 64 substeps or more the skin halves (down to skin_min).  A scene that moves fast gets fatter
-    // cells and longer lists instead of a rebuild per substep, a quiet one gets them lean again.
-    float cell, reach2; // cell width 2r*(1+1/64) + 2*skin (>= cell_min); (2r + 2*skin)^2 with a rounding margin
+struct SbGridGeom {
+    float skin, cell, reach2; // cell width 2r*(1+1/64) + 2*skin (>= cell_min); (2r + 2*skin)^2 with a rounding margin
     uint32_t nx, ny;
     float x0, y0;       // origin of the frame in use
     uint32_t wide;      // 0: tight frame; 1: whole domain (more than 1/64 of the particles fell outside the tight one)
-    uint32_t since;     // substeps the current hash has served
-    float skin_min, skin_max;
-    uint32_t wide_next; // 1: the last build counted more than 1/64 of the particles outside its frame, so the NEXT build
-                        //    frames the whole domain.  Written by ONE thread (block 0, after the build's first device-wide
-                        //    barrier) and read by every workgroup of a LATER launch: the decision has a single source.
+    uint32_t gen;       // number of the build this hash came from (what its head words carry)
 };
-struct SbGridGeom {
-    float skin, cell, reach2;
-    uint32_t nx, ny;
-    float x0, y0;
-    uint32_t wide;
-    uint32_t gen; // number of the build the current hash came from (SbGridCtl::builds)
+// The decision state, one block per substep parity.  r04: the block a substep kernel reads was published by the LAST WORKGROUP TO
+// FINISH of the substep before it (sb_grid_tail: per-workgroup displacement slots, sharded arrival tickets, the last arriver
+// reduces and decides) -- until r03 a helper launch per substep (k_grid_maintain) did that, 18 % of config 3's GPU time for a
+// decision that is "nothing to do" on nine substeps in ten.  A launch reads ctl[par] with plain loads (written by an earlier
+// launch) and its tail writes ctl[par ^ 1] whole.  Two schedules for the hash itself (the `mode` of a launch, the host's choice):
+//   SB_GRID_LAGGED   no helper launch at all.  When the bound is about to run out (D + 2 x the last step > skin) the tail ORDERS
+//                    a push: during the next substep every workgroup pushes its own particles (READ state) into the OTHER hash
+//                    buffer while the lists in use -- still valid -- serve that substep; the substep after that makes the new
+//                    lists (fresh), which are born with the push substep's displacement already on their bound.  Kernel
+//                    boundaries are the only synchronisation: no device-wide barrier, no residency requirement, any number of
+//                    tiles.  If a single substep moves somebody farther than predicted (lists invalid and no hash in the
+//                    making, or new lists invalid at birth) the tail raises `abort`: that launch has still produced a correct
+//                    substep -- its lists were valid -- but every launch queued behind it returns at once, and the host, which
+//                    looks at the end of every call, builds a hash with the helper and runs a stretch in the classic schedule.
+//   SB_GRID_CLASSIC  the r03 schedule: `fresh` + `need_build` ask the helper launch in front of the next substep
+//                    (k_grid_build, which otherwise returns at once) for a hash of that substep's READ state.  Violent scenes
+//                    (a hash per substep or two) and the atomic path run this way.
+// A rebuild the HOST knows about (upload, ghost refresh, the hybrid's fresh start, recovery from an abort) is a forced helper
+// launch, not a flag.
+#define SB_GRID_LAGGED 0u
+#define SB_GRID_CLASSIC 1u
+struct SbGridCtl {
+    uint32_t fresh;      // the coming substep makes the neighbour lists from hash `cur` ...
+    uint32_t need_build; // ... which the helper launch in front of it has yet to build (classic schedule only)
+    uint32_t pushing;    // the coming substep pushes every particle into hash cur ^ 1, geometry `pgeo` (lagged schedule only)
+    uint32_t abort;      // sticky, in BOTH blocks: the lists are not known to be valid for the coming substep; launches return at once
+    uint32_t cur;        // the hash buffer the lists in use came from
+    uint32_t executed;   // substeps run since the upload (the host's roll-back after an abort counts on it)
+    uint32_t builds;     // statistics: hashes built (or on order)
+    uint32_t since;      // substeps the lists in use have served, the coming one included
+    float accum;         // D for the READ state of the coming substep
+    float cx, cy;        // c for the coming substep
+    float Cx, Cy;        // C for the READ state of the coming substep
+    float skin_min, skin_max; // the skin ADAPTS at every build: when the last hash lasted 3 substeps or less it doubles (up to
+                         // skin_max) provided that promises two substeps at the rate the bound has been growing -- if not even
+                         // that, the scene is too violent for any hash to last and the skin drops back to skin_min; when a hash
+                         // lasted 64 substeps or more the skin halves (down to skin_min)
+    uint32_t wide_next;  // 1: some build counted more than 1/64 of the particles outside its frame: the next one frames the whole domain
+    uint32_t settled;    // 1: the displacement slots of the last substep are already in `accum` (or the lists were replaced since): the
+                         // decision of the coming substep does not add them again (forced helper launch, k_grid_settle, the hybrid's write-back)
+    uint32_t pad_;
+    SbGridGeom geo;      // hash `cur`
+    SbGridGeom pgeo;     // hash cur ^ 1 while it is being pushed
 };
+static_assert(sizeof(SbGridCtl) % 16 == 0, "SbGridCtl is moved in 16-byte chunks");
 #define SB_CHAIN_END 0xFFFFFFFFu
 #define SB_MAX_WAVES 16
 #define SB_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -506,7 +536,7 @@ struct SbGridGeom {
 #define SB_CTL_LOAD(p) (*(p))
 #define SB_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-SB_DEV SbGridGeom sb_grid_geom_load(const SbGridCtl *c)
+SB_DEV SbGridGeom sb_grid_geom_load(const SbGridGeom *c)
 {
     SbGridGeom m;
     m.skin = SB_CTL_LOAD(&c->skin);
@@ -517,8 +547,22 @@ SB_DEV SbGridGeom sb_grid_geom_load(const SbGridCtl *c)
     m.x0 = SB_CTL_LOAD(&c->x0);
     m.y0 = SB_CTL_LOAD(&c->y0);
     m.wide = SB_CTL_LOAD(&c->wide);
-    m.gen = SB_CTL_LOAD(&c->builds);
+    m.gen = SB_CTL_LOAD(&c->gen);
     return m;
+}
+// the hash the lists in use came from, as a view: buffer `cur` in the first three members, its geometry, the drift since its build
+SB_DEV SbGrid sb_grid_view(const SbGrid &g, uint32_t cur, const SbGridGeom *geo, float Cx, float Cy)
+{
+    SbGrid v = g;
+    v.geo = geo;
+    v.Cx = Cx;
+    v.Cy = Cy;
+    if (cur != 0u) {
+        v.head = g.head1;
+        v.rec = g.rec1;
+        v.cell_of = g.cell_of1;
+    }
+    return v;
 }
 // the geometry that goes with a skin (every workgroup of k_grid_maintain computes the same values)
 SB_DEV SbGridGeom sb_grid_geom_for(const SbGrid &g, float skin, uint32_t wide)
@@ -547,11 +591,76 @@ SB_DEV SbGridGeom sb_grid_geom_for(const SbGrid &g, float skin, uint32_t wide)
     return m;
 }
 
-// End of the particle kernel, called by EVERY thread of the block: this block's largest drift-relative
-// displacement goes to blk[blockIdx.x] (float bits; anything not provably small reads as huge).  One plain slot
-// per workgroup: funnelling ~1000 workgroups through atomics on one address cost ~50 us per launch
-// (same-address atomics retire one per ~12 ns).  k_grid_maintain reduces the slots.
-SB_DEV void sb_store_block_displacement(uint32_t *blk, float m)
+// ---- the start of every particle kernel under SB_COLLIDE_GRID: last substep's displacement slots, the decision (SbGridCtl)
+// Every workgroup takes the SAME decision from the same words, in the shadow of its own first loads -- what the helper launch
+// of rounds 1-3 did, as the prologue of the kernel that needs the answer.  (r04 first put the decision at the END of the
+// substep kernel -- arrival tickets, the last workgroup reduces and publishes: five dependent trips to memory at ~1 us each
+// behind the last workgroup's last store made every launch 9 us longer; profiles/r04_grid_schedules.txt.  Nothing may hang off
+// the end of a launch that fills the chip exactly once.)
+//   slots: float4[3][SB_GRID_SLOTS] = {largest drift-relative displacement (float bits, by atomic max: order-free), sample dx,
+//   sample dy, -} of the workgroups b with b % SB_GRID_SLOTS == slot (samples: the first SB_GRID_SLOTS workgroups only).
+//   Triple buffered by the number of the substep: substep k reads buffer (k - 1) % 3, fills k % 3, and its workgroup 0 zeroes
+//   (k + 1) % 3 -- all three indices come from the HOST's count of executed substeps, which an abort corrects.
+#define SB_GRID_SLOTS 64u // (one wave reduces them all; a thousand workgroups: fifteen atomic maxima per slot, spread over the launch)
+struct SbGridStep {
+    SbGridCtl *ctl;           // both parity blocks
+    uint32_t par;             // the block the substep before this one published; workgroup 0 of this launch publishes the other
+    uint32_t mode;            // SB_GRID_LAGGED / SB_GRID_CLASSIC
+    const float4 *slots_in;   // what the substep before this one measured
+    float4 *slots_out;        // what this one measures
+    float4 *slots_zero;       // the buffer the next one fills
+    float inv_samples;        // 1 / min(workgroups of the particle kernel, SB_GRID_SLOTS)
+    uint32_t *outside;        // [4] particles each build found outside its frame, by build number & 3 (sb_grid_decide)
+    uint32_t P;
+#ifdef SB_STAMPS // diagnostic build: where one workgroup's time goes (10 ns ticks since its start; tools/grid_schedule_probe.py)
+    uint32_t *stamps;
+#endif
+};
+#ifdef SB_STAMPS
+#define SB_STAMP(t, k)                                                                                                  \
+    do {                                                                                                                \
+        if (blockIdx.x == gridDim.x / 2u && threadIdx.x == 0u) (t).stamps[k] = (uint32_t)(wall_clock64() - sb_t_start); \
+    } while (0)
+#else
+#define SB_STAMP(t, k) do { } while (0)
+#endif
+// The words of the decision that gate the kernel itself, and the numbers every thread needs of it.  ONE lane per workgroup
+// computes them (sb_grid_stage: a few dozen instructions in front of the first barrier, while the other waves are still
+// waiting for their own loads); everybody reads them behind that barrier.  r04 measured what the alternatives cost on a kernel
+// that is bound by instruction issue: every wave computing them for itself (a dozen LDS reads, two divisions: 130 instructions
+// x 32 waves per CU) +4 us per launch; thread 0 computing the WHOLE block with the workgroup waiting at a second barrier +4 us
+// as well (profiles/r04_grid_schedules.txt).
+struct SbGridFlags {
+    uint32_t abort, fresh, pushing, need_build;
+};
+struct SbGridHot {
+    SbGridFlags f;
+    float step;       // the largest drift-relative displacement of the substep just done
+    float cx, cy;     // the common displacement this substep is measured against
+    float Cx, Cy;     // the drift accumulated since the hash in use was built -- meaningful on a substep that neither makes lists nor
+                      // aborts (the cell scans of particles whose lists overflowed use it); on the others: SbGridShared::now
+    uint32_t pad_[3];
+};
+struct __attribute__((aligned(16))) SbGridShared { // LDS of a kernel that decides
+    uint32_t outside[4]; // the builders' counts (SbGridStep::outside)
+    SbGridHot hot;
+    SbGridCtl prev;    // the block the launch read
+    SbGridCtl now;     // what it runs under -- in workgroup 0, which publishes it, and wherever a substep makes lists or pushes
+};
+
+// The scene's common drift is estimated from a SAMPLE: the first particle of each of the first SB_GRID_SLOTS workgroups reports
+// its displacement; any estimate keeps the bound valid.  Called by thread 0.
+SB_DEV void sb_store_sample_displacement(float4 *slots_out, float dx, float dy)
+{
+    if (blockIdx.x < SB_GRID_SLOTS) {
+        slots_out[blockIdx.x].y = sb_abs(dx) < 1.0e30f ? dx : 0.0f;
+        slots_out[blockIdx.x].z = sb_abs(dy) < 1.0e30f ? dy : 0.0f;
+    }
+}
+
+// End of the particle kernel, called by EVERY thread: this workgroup's largest drift-relative displacement joins its slot
+// (anything not provably small reads as huge; non-negative floats order like their bits).  Fire and forget: nothing waits for it.
+SB_DEV void sb_store_block_displacement(float4 *slots_out, float m)
 {
     __shared__ float s_wave_max[SB_MAX_WAVES];
     m = (m < 1.0e30f) ? m : 1.0e30f;
@@ -562,17 +671,202 @@ SB_DEV void sb_store_block_displacement(uint32_t *blk, float m)
     if (threadIdx.x == 0) {
         float b = 0.0f;
         for (uint32_t w = 0; w < (blockDim.x >> 6); w++) b = fmaxf(b, s_wave_max[w]);
-        SB_AGENT_STORE(&blk[blockIdx.x], __float_as_uint(b));
+        (void)__hip_atomic_fetch_max((uint32_t *)&slots_out[blockIdx.x % SB_GRID_SLOTS].x, __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// The scene's common drift is estimated from a SAMPLE: the first particle of every workgroup reports its
-// displacement (blk[nblk + blockIdx.x], blk[2*nblk + blockIdx.x]); any estimate keeps the bound valid.
-SB_DEV void sb_store_sample_displacement(uint32_t *blk, uint32_t nblk, float dx, float dy)
+// the skin of the hash about to be built follows how long the last one lasted (SbGridCtl)
+SB_DEV float sb_grid_next_skin(float skin, float skin_min, float skin_max, float accum, uint32_t since)
 {
-    SB_AGENT_STORE(&blk[nblk + blockIdx.x], __float_as_uint(sb_abs(dx) < 1.0e30f ? dx : 0.0f));
-    SB_AGENT_STORE(&blk[2u * nblk + blockIdx.x], __float_as_uint(sb_abs(dy) < 1.0e30f ? dy : 0.0f));
+    if (since <= 3u) {
+        // short-lived hash: a doubled skin must promise at least two substeps at the rate the bound has been
+        // growing, else the scene is simply too violent for any hash to last and lean cells are the cheapest
+        const float rate = accum / (float)since, wider = fminf(skin * 2.0f, skin_max);
+        if (wider >= 2.0f * rate) return wider;
+        if (!(skin >= 2.0f * rate)) return skin_min;
+    } else if (since >= 64u) {
+        return fmaxf(skin * 0.5f, skin_min);
+    }
+    return skin;
 }
+
+// Requested by every thread together with its own particles (cold lines, a full trip to memory like them; the wait counter
+// retires in order, so asked for any earlier they would stand in front of requests that come out of the L2).  Unconditional
+// (an exec-masked load is a branch with a full drain of the wait counter behind it); only wave 0's copies are used: lane k its
+// slot, lanes 0 .. 8 the control block in 16-byte chunks, lane 9 the four `outside` counters.  Everything the decision reads
+// comes in with these two requests: a load of its own inside the decision would be a memory latency with the whole workgroup
+// waiting behind it.
+struct SbGridEarly {
+    float4 slot, ctl;
+};
+SB_DEV SbGridEarly sb_grid_begin(const SbGridStep &t)
+{
+    SbGridEarly e;
+    e.slot = t.slots_in[threadIdx.x % SB_GRID_SLOTS];
+    const uint32_t chunks = sizeof(SbGridCtl) / 16u, lane = threadIdx.x & 63u, k = lane < chunks ? lane : chunks;
+    const float4 *ctl = (const float4 *)(t.ctl + t.par), *cnt = (const float4 *)t.outside;
+    e.ctl = (k < chunks ? ctl : cnt - chunks)[k];
+    return e;
+}
+
+// the flags of this substep from those of the block it read and the displacement of the substep just done
+SB_DEV SbGridFlags sb_grid_flags(uint32_t e_abort, uint32_t e_settled, uint32_t e_fresh, uint32_t e_pushing, uint32_t e_need_build,
+                                 float e_accum, float skin, float pskin, float step, uint32_t mode, uint32_t advance)
+{
+    SbGridFlags f{e_abort, e_fresh, e_pushing, e_need_build}; // (adopted as they stand: abort is sticky, a settled block was decided ahead of time)
+    if (e_abort == 0u && e_settled == 0u) {
+        const float accum1 = e_accum + step; // the bound of the lists in use, for the READ state of this substep
+        const bool over = !(accum1 <= skin); // NaN-safe
+        f.fresh = f.pushing = f.need_build = 0u;
+        if (e_pushing != 0u) { // the substep just done pushed ITS read state into hash cur ^ 1: this one makes the lists, born
+            f.fresh = 1u;      // with that substep's displacement on their bound
+            if (!(step <= pskin)) f.abort = 1u;
+        } else if (mode == SB_GRID_CLASSIC) {
+            if (over) f.fresh = f.need_build = 1u; // the helper launch in front of this substep builds from its READ state (it takes this same decision)
+        } else if (over) {
+            f.abort = 1u; // somebody moved farther than predicted: the lists in use are not known to be valid any more
+        } else if (!(accum1 + 2.0f * step <= skin)) {
+            f.pushing = 1u; // one more substep like the last could use the skin up: this substep pushes the next hash as it goes
+        }
+    }
+    // a lagged launch cannot serve a build the classic schedule ordered from a helper it does not have (the host changed
+    // schedules without serving it: never, by construction)
+    if (mode == SB_GRID_LAGGED && advance != 0u && f.need_build != 0u) f.abort = 1u;
+    return f;
+}
+
+// In front of the kernel's first workgroup barrier, by wave 0 (the caller's other waves pass through): the slots reduced, the
+// block and the counters into LDS, and -- lane 0 -- what everybody needs of the decision (SbGridHot).
+SB_DEV void sb_grid_stage(const SbGridStep &t, const SbGridEarly &e, SbGridShared &sh, uint32_t advance)
+{
+    if (threadIdx.x >= 64u) return;
+    const uint32_t lane = threadIdx.x, chunks = sizeof(SbGridCtl) / 16u;
+    float mx = e.slot.x, sx = e.slot.y, sy = e.slot.z; // (non-negative floats order like their bits: the atomic maximum was taken on those)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        sx += __shfl_xor(sx, off, 64);
+        sy += __shfl_xor(sy, off, 64);
+    }
+    if (lane < chunks) {
+        ((float4 *)&sh.prev)[lane] = e.ctl;
+        ((float4 *)&sh.now)[lane] = e.ctl; // (the decision starts from a copy and patches it in place)
+    } else if (lane == chunks) {
+        *(float4 *)sh.outside = e.ctl;
+    }
+    // the words of the block the flags depend on, out of the lanes that hold them (a word of chunk c sits in lane c)
+#define SB_CTL_WORD(field) __builtin_amdgcn_readlane(__float_as_uint(((offsetof(SbGridCtl, field) / 4u) & 3u) == 0u   ? e.ctl.x \
+                                                                      : ((offsetof(SbGridCtl, field) / 4u) & 3u) == 1u ? e.ctl.y \
+                                                                      : ((offsetof(SbGridCtl, field) / 4u) & 3u) == 2u ? e.ctl.z \
+                                                                                                                        : e.ctl.w), \
+                                                     (int)(offsetof(SbGridCtl, field) / 16u))
+    const uint32_t e_abort = SB_CTL_WORD(abort), e_settled = SB_CTL_WORD(settled), e_fresh = SB_CTL_WORD(fresh);
+    const uint32_t e_pushing = SB_CTL_WORD(pushing), e_need = SB_CTL_WORD(need_build);
+    const float e_accum = __uint_as_float(SB_CTL_WORD(accum)), skin = __uint_as_float(SB_CTL_WORD(geo.skin));
+    const float pskin = __uint_as_float(SB_CTL_WORD(pgeo.skin));
+    const float e_cx = __uint_as_float(SB_CTL_WORD(cx)), e_cy = __uint_as_float(SB_CTL_WORD(cy));
+    const float e_Cx = __uint_as_float(SB_CTL_WORD(Cx)), e_Cy = __uint_as_float(SB_CTL_WORD(Cy));
+#undef SB_CTL_WORD
+    if (lane == 0u) {
+        SbGridHot h;
+        h.step = mx;
+        h.f = sb_grid_flags(e_abort, e_settled, e_fresh, e_pushing, e_need, e_accum, skin, pskin, mx, t.mode, advance);
+        if (e_abort != 0u || e_settled != 0u) { // adopted as it stands
+            h.cx = e_cx;
+            h.cy = e_cy;
+            h.Cx = e_Cx;
+            h.Cy = e_Cy;
+        } else { // the mean of the sample displacements of the substep just done
+            float mean_x = sx * t.inv_samples, mean_y = sy * t.inv_samples;
+            if (!(sb_abs(mean_x) < 1.0e30f) || !(sb_abs(mean_y) < 1.0e30f)) mean_x = mean_y = 0.0f;
+            h.cx = mean_x;
+            h.cy = mean_y;
+            h.Cx = e_Cx + e_cx;
+            h.Cy = e_Cy + e_cy;
+        }
+        h.pad_[0] = h.pad_[1] = h.pad_[2] = 0u;
+        sh.hot = h;
+    }
+}
+
+// The state this substep runs under (see SbGridCtl for the two schedules), by ONE thread, into sh.now (a copy of sh.prev so
+// far: sb_grid_stage), behind the kernel's first barrier; whoever reads sh.now has another barrier in front of that.  Every
+// workgroup of a launch computes the same block: everything read here was written by earlier launches.
+//   advance   1: a substep (it counts itself); 0: the host's settling launch (k_grid_settle: the decision ahead of time, for a
+//             look) -- the block it publishes is `settled`, and the substep that finds it adopts it as it stands
+//   publish   workgroup 0 stores the block for the next launch (the unforced helper decides too, but only for itself)
+// outside[4]: particles each build found outside its frame, by build number & 3: the builders of hash G add to slot G & 3, the
+// decision reads the slot of the hash in use (complete long ago) and whoever orders hash G zeroes slot (G + 1) & 3.
+SB_DEV void sb_grid_decide(const SbGridStep &t, const SbGrid &g, SbGridShared &sh, uint32_t advance, bool publish)
+{
+    const SbGridCtl &E = sh.prev;
+    SbGridCtl &N = sh.now; // (patched in LDS, field by field, so that this once-per-launch code does not size the kernel's register file)
+    const float step = sh.hot.step; // (lane 0 of wave 0 computed them in front of the barrier: sb_grid_stage)
+    const SbGridFlags f = sh.hot.f;
+    if (E.abort != 0u) {
+        // sticky: nothing moves until the host has been here
+    } else if (E.settled != 0u) {
+        N.settled = advance ? 0u : 1u;
+        N.executed = E.executed + advance;
+    } else {
+        // the frame: tight until some build found more than 1/64 of the particles outside it
+        const uint32_t wide_next = (E.wide_next != 0u || sh.outside[E.geo.gen & 3u] > t.P / 64u) ? 1u : 0u;
+        const float accum1 = E.accum + step;
+        N.wide_next = wide_next;
+        N.fresh = f.fresh;
+        N.need_build = f.need_build;
+        N.pushing = f.pushing;
+        N.settled = advance ? 0u : 1u;
+        N.executed = E.executed + advance;
+        N.cx = sh.hot.cx;
+        N.cy = sh.hot.cy;
+        // unless something below says otherwise: the lists in use serve this substep too
+        N.since = E.since + 1u;
+        N.accum = accum1;
+        N.Cx = E.Cx + E.cx;
+        N.Cy = E.Cy + E.cy;
+        auto order = [&](SbGridGeom &out) { // the geometry of a hash to come (the skin adapts to how long this one lasted)
+            const float skin_new = sb_grid_next_skin(E.geo.skin, E.skin_min, E.skin_max, accum1, E.since);
+            out = sb_grid_geom_for(g, skin_new, (E.geo.wide != 0u || wide_next != 0u) ? 1u : 0u);
+            out.gen = E.builds + 1u;
+            N.builds = E.builds + 1u;
+            if (publish && blockIdx.x == 0u) SB_AGENT_STORE(&t.outside[(E.builds + 2u) & 3u], 0u);
+        };
+        if (E.pushing != 0u) { // lists from the hash the last substep pushed
+            N.cur = E.cur ^ 1u;
+            N.geo = E.pgeo;
+            N.since = 1u;
+            N.accum = step;
+            N.Cx = E.cx;
+            N.Cy = E.cy;
+        } else if (f.need_build != 0u) { // (classic: the helper builds hash cur ^ 1 with this geometry)
+            order(N.geo);
+            N.cur = E.cur ^ 1u;
+            N.since = 1u;
+            N.accum = N.Cx = N.Cy = 0.0f;
+        } else if (f.pushing != 0u) {
+            order(N.pgeo);
+        }
+    }
+    if (f.abort != 0u && E.abort == 0u) {
+        N.abort = 1u;
+        N.executed = E.executed; // (this launch returns at once)
+    }
+    if (publish && blockIdx.x == 0u) {
+        const uint32_t *src = (const uint32_t *)&sh.now;
+        uint32_t *dst = (uint32_t *)(t.ctl + (t.par ^ 1u));
+        for (uint32_t k = 0; k < sizeof(SbGridCtl) / 4u; k++) SB_AGENT_STORE(&dst[k], src[k]);
+        if (f.abort != 0u) SB_AGENT_STORE(&t.ctl[t.par].abort, 1u); // both blocks: later launches alternate between them
+    }
+}
+
+// the arrays a build writes (both hash buffers)
+struct SbGridBuild {
+    unsigned long long *head[2];
+    uint32_t *cell_of[2];
+    float4 *rec[2];
+    uint32_t *outside; // [4] particles each build found outside its frame, by build number & 3 (sb_grid_decide)
+};
 
 // cell coordinate with the clamp made visible: *outside is set when a FINITE coordinate had to be clamped
 SB_DEV uint32_t sb_grid_coord_flag(float x, float x0, float cell, uint32_t n, bool *outside)
@@ -596,6 +890,41 @@ SB_DEV uint32_t sb_grid_coord(float x, float x0, float cell, uint32_t n)
     if (q >= (float)n) return n - 1u;
     return (uint32_t)q;
 }
+
+// One particle into hash buffer `buf`, in two halves so that a caller can keep several returning atomics in flight per lane:
+// its cell and itself pushed on the front of that cell's list with one returning 64-bit exchange (the head word carries the
+// number of the build, so the cells of older builds read as empty and nothing is ever cleared; the order inside a list is
+// arbitrary, which is fine: contacts are re-ordered by slot) ...
+SB_DEV unsigned long long sb_grid_push_begin(const SbGridBuild &w, uint32_t buf, const SbGridGeom &geo, uint32_t i, float2 p,
+                                             uint32_t *cell, bool *outside)
+{
+    *cell = sb_grid_coord_flag(p.y, geo.y0, geo.cell, geo.ny, outside) * geo.nx + sb_grid_coord_flag(p.x, geo.x0, geo.cell, geo.nx, outside);
+    return atomicExch(&w.head[buf][*cell], ((unsigned long long)geo.gen << 32) | i);
+}
+// ... then its record, whose `next` is what the exchange returned if that came from the same build
+SB_DEV void sb_grid_push_end(const SbGridBuild &w, uint32_t buf, const SbGridGeom &geo, uint32_t i, float2 p, uint32_t slot,
+                             uint32_t cell, unsigned long long old)
+{
+    const uint32_t next = (uint32_t)(old >> 32) == geo.gen ? (uint32_t)old : SB_CHAIN_END;
+    w.cell_of[buf][i] = cell;
+    w.rec[buf][i] = make_float4(p.x, p.y, __uint_as_float(slot), __uint_as_float(next));
+}
+
+// the builders' count of particles outside the frame (slot: build number & 3): one add per wave, and only when somebody left
+// it; read by the decisions of later launches only
+SB_DEV void sb_grid_count_outside(uint32_t *outside_slot, uint32_t n_out)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_out += __shfl_xor(n_out, off, 64);
+    if (n_out && (threadIdx.x & 63u) == 0u) (void)__hip_atomic_fetch_add(outside_slot, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what a particle kernel under SB_COLLIDE_GRID gets besides the hash itself
+struct SbGridJob {
+    SbGridStep step;
+    SbGridBuild build;     // lagged schedule: the arrays a push writes
+    const uint32_t *pslot; // ... and every particle's slot (its record carries it)
+};
 
 // The hash is a linked list per cell (r02; round 1 counted, scanned and scattered into cell-sorted records: three
 // device-wide barriers and a scan over every cell, 70-90 us per build against ~20 for one pass of exchanges): the first
@@ -658,7 +987,7 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridHo
     const float far2 = two_r * two_r * 1.001f;
     const float reach = two_r + m.skin, stale_far2 = reach * reach * 1.001f;
     // where this particle would be in the frame of the build: current position minus the common drift
-    const float qx = self.p.x - SB_CTL_LOAD(&g.ctl->Cx), qy = self.p.y - SB_CTL_LOAD(&g.ctl->Cy);
+    const float qx = self.p.x - g.Cx, qy = self.p.y - g.Cy;
     bool have_last = false;
     uint32_t last = 0u;
     for (;;) {
@@ -707,9 +1036,13 @@ SB_DEV void sb_collide_grid(const SbGrid &g, const SbGridGeom &m, const SbGridHo
 // in ascending slot order (repeated selection of the smallest slot above the last one taken, as above).
 // While the displacement bound D <= skin, a pair closer than 2r NOW was closer than 2r + 2D at build time,
 // so the list is a superset of i's contacts until the next build.  NaN distances are kept (conservative).
-SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, uint32_t i, float2 p)
+SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, uint32_t i)
 {
     const float reach2 = m.reach2;
+    // distances AT BUILD TIME, record against record: in the lagged schedule (SbGridCtl) the hash holds the READ state of the
+    // substep before this one, so the particle's own current position is not the one its neighbours were binned against
+    const float4 own = g.rec[i];
+    const float2 p = make_float2(own.x, own.y);
     const SbGridHood hood = sb_grid_hood(g, m, g.cell_of[i]);
     uint32_t n = 0u, last = 0u;
     bool have_last = false;
@@ -809,8 +1142,8 @@ SB_DEV void sb_collide_slow(const SbGrid &g, bool fresh, const SbParams &prm, fl
                             const uint32_t *__restrict__ pidx, const float2 *__restrict__ pos_r,
                             const float2 *__restrict__ vel_r)
 {
-    const SbGridGeom m = sb_grid_geom_load(g.ctl); // only these paths need the geometry of the current hash
-    const uint32_t count = fresh ? sb_neighbour_list_build(g, m, i, self.p) : g.nl_count[i];
+    const SbGridGeom m = sb_grid_geom_load(g.geo); // only these paths need the geometry of the current hash
+    const uint32_t count = fresh ? sb_neighbour_list_build(g, m, i) : g.nl_count[i];
     if (count == SB_NL_OVERFLOW) {
         const SbGridHood hood = sb_grid_hood(g, m, g.cell_of[i]);
         sb_collide_grid(g, m, hood, prm, friction, elasticity_coeff, particle, self, i, pidx, pos_r, vel_r);
