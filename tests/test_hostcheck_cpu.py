@@ -1,0 +1,63 @@
+"""The host side of the C library under sanitizers (`make -C softbody-webgpu_amd/csrc hostcheck`): the scene
+partitioner (csrc/sb_partition.cpp, driven by tests/partition_check.cpp on the reference's default scene, main.ts:188-246, and
+on a 90 000-particle lattice, v1 and v2 layouts) and the two multi-threaded upload planners (sb_tiling.h, sb_blocking.h with the
+check drivers of tests/test_tiling_cpu.py / test_blocking_cpu.py), each built with AddressSanitizer + UBSan and with
+ThreadSanitizer.  CPU only: the GPU pool has no sanitizers."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "softbody-webgpu_amd", "csrc")
+BUILD = os.path.join(CSRC, "hostcheck_build")
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+           TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+
+
+@pytest.fixture(scope="module")
+def built():
+    p = subprocess.run(["make", "-C", CSRC, "hostcheck", "-j4"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return BUILD
+
+
+def dump(buf, path):
+    with open(path, "wb") as f:
+        np.array([buf.layout, buf.max_particles, buf.max_beams, 0], "<u4").tofile(f)
+        for a in (buf.metadata, buf.mapping, buf.particles, buf.beams):
+            a.tofile(f)
+
+
+def run(exe, args, timeout=600):
+    p = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout, env=ENV)
+    assert p.returncode == 0 and "Sanitizer" not in p.stderr, (exe, p.stdout[-2000:], p.stderr[-4000:])
+    return p.stdout
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_partitioner_under_sanitizers(built, sb, tmp_path, san):
+    scenes = {"default_v1": sb.scenes.default_buffers(1, 256, 512), "default_v2": sb.scenes.default_buffers(2, 200, 400),
+              "lattice_90k": sb.scenes.lattice_buffers(300, 300, d=30.0, jitter=1.0, layout=2, slack=7)}
+    # a scene whose mapping is not the identity (compute_delete permutes it, engineMapping.ts:336-339): slots reversed
+    perm = sb.scenes.default_buffers(2, 200, 400)
+    P, B = perm.particle_count, perm.beam_count
+    perm.mapping[:P] = perm.mapping[:P][::-1].copy()
+    perm.mapping[perm.max_particles:perm.max_particles + B] = perm.mapping[perm.max_particles:perm.max_particles + B][::-1].copy()
+    scenes["default_permuted"] = perm
+    for name, buf in scenes.items():
+        path = str(tmp_path / (name + ".bin"))
+        dump(buf, path)
+        out = run(os.path.join(built, "partition_check_" + san), [path])
+        assert "PARTITION_OK %d particles %d beams" % (buf.particle_count, buf.beam_count) in out, (name, out)
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_planners_under_sanitizers(built, san):
+    # (the same parameter sets as tests/test_blocking_cpu.py / test_tiling_cpu.py, one lattice and one random graph each)
+    for args in (("60", "40", "256", "1", "0", "4"), ("40", "30", "128", "4", "1", "4")):
+        assert "BLOCKING_OK" in run(os.path.join(built, "blocking_check_" + san), args)
+    for args in (("100", "80", "1024", "1", "0"), ("60", "50", "256", "4", "1"), ("300", "300", "1024", "5", "0")):
+        assert "TILING_OK" in run(os.path.join(built, "tiling_check_" + san), args)
