@@ -16,9 +16,24 @@
  *     ArrayBuffers are owned and later mutated by BufferMapper,
  *     engineMapping.ts:364-367).
  *   - one call at a time per engine, like the reference's AsyncLock
- *     (src/lock.ts:4-19; engineWorker.ts:553,584,632).  sb_step/sb_frame only
- *     enqueue work on the engine's HIP stream; sb_sync, sb_load_buffers and
- *     sb_step_timed wait for it.
+ *     (src/lock.ts:4-19; engineWorker.ts:553,584,632).  When do calls return?
+ *       SB_COLLIDE_OFF / SB_COLLIDE_ALLPAIRS, and SB_PATH_ATOMIC with any collision mode:
+ *         sb_step / sb_frame / sb_delete_pass only ENQUEUE work on the engine's HIP stream;
+ *         sb_sync, sb_load_buffers and sb_step_timed wait for it.
+ *       SB_COLLIDE_GRID on the tiled path (the default of sb_default_options): sb_step and
+ *         sb_frame MAY WAIT for the stream, like every call of the reference does
+ *         (engineWorker.ts:632-633,686-688: `await queue.onSubmittedWorkDone()` on both
+ *         sides of a frame).  The spatial hash keeps itself valid on the device; what
+ *         the host owes it is one look when a call's substeps have been issued (did a
+ *         substep move somebody farther than predicted?  -- then the launches behind it
+ *         returned at once and are issued again behind a fresh hash), and the stretches
+ *         that run several substeps per launch (nothing within reach of anything) are
+ *         sized from a look at the device as well.  So a call returns when its LAST
+ *         substep has been issued and everything before the last look has run: for a
+ *         1 M-particle scene a 64-substep frame holds the calling thread for about
+ *         2.4 ms of its 2.4 ms (a Node host should call from a worker thread, as the
+ *         reference itself does: engine.ts:138).  sb_delete_pass, sb_write_user_input
+ *         and the sb_halo_* / sb_peer_* calls still only enqueue.
  *   - there is no CPU fallback: without a usable HIP device sb_create fails.
  */
 #ifndef SOFTBODY_H

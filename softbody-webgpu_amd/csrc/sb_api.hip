@@ -1350,22 +1350,37 @@ static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
         const bool stretch = sched == SB_GRID_CLASSIC && e->grid_classic_left != 0u;
         const uint32_t chunk = stretch ? std::min(m, e->grid_classic_left) : m, exec0 = e->grid_executed;
         for (uint32_t i = 0; i < chunk; i++) sbk_launch_substep(e, aux_on_last && i + 1 == m);
+        SbGridCtl *pin = (SbGridCtl *)(e->dev_err + 96); // (pinned; hybrid_substeps uses words 16 .. 95)
         if (sched == SB_GRID_CLASSIC) { // (its decisions never abort: the helper serves whatever they order)
-            if (stretch) e->grid_classic_left -= chunk;
             e->grid_classic_substeps += chunk;
             m -= chunk;
+            if (!stretch) continue; // (the atomic path, SB_GRID_MODE=classic: always)
+            e->grid_classic_left -= chunk;
+            if (e->grid_classic_left == 0u) { // end of a stretch: is the scene still one that wears a hash out in a few substeps?
+                SB_HIP(e, hipMemcpyAsync(pin, e->d_grid_ctl + e->grid_par, sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
+                SB_HIP(e, hipStreamSynchronize(e->stream));
+                if (pin[0].short_lived != 0u) {
+                    e->grid_classic_chunk = std::min(2u * e->grid_classic_chunk, 1024u);
+                    e->grid_classic_left = e->grid_classic_chunk;
+                }
+            }
             continue;
         }
-        SbGridCtl *pin = (SbGridCtl *)(e->dev_err + 96); // (pinned; hybrid_substeps uses words 16 .. 95)
         SB_HIP(e, hipMemcpyAsync(pin, e->d_grid_ctl, 2 * sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
         SB_HIP(e, hipStreamSynchronize(e->stream));
         if (!(pin[0].abort | pin[1].abort)) {
+            m -= chunk;
+            if (pin[e->grid_par].short_lived != 0u) { // hashes last four substeps or less: the classic schedule serves such a scene better
+                e->grid_classic_chunk = std::max(64u, e->grid_classic_chunk);
+                e->grid_classic_left = e->grid_classic_chunk;
+                e->grid_calm = 0;
+                continue;
+            }
             e->grid_calm += chunk;
             if (e->grid_calm >= 1024u && e->grid_classic_chunk) { // calm for a while: the next abort starts with a shorter stretch
                 e->grid_classic_chunk /= 2u;
                 e->grid_calm = 0;
             }
-            m -= chunk;
             continue;
         }
         // the launches that ran are the ones that counted themselves; the rest returned at once
@@ -1898,10 +1913,20 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
             *value = n;
         }
     }
-    else if (k.rfind("grid_stamp_", 0) == 0) { // phase stamps of block 0 in the last hash build, 10 ns ticks since its start (diagnostic)
+    else if (k.rfind("grid_stamp_", 0) == 0) { // -DSB_STAMPS builds: stamps of one mid-grid workgroup of the last substep launch, 10 ns ticks since its start (diagnostic)
         const int i = atoi(key + 11);
         SB_HIP(e, hipStreamSynchronize(e->stream));
         *value = (i >= 0 && i < 7 && e->dev_err) ? e->dev_err[4 + i] : 0;
+    }
+    else if (k.rfind("grid_ctl_", 0) == 0) { // word <n> of the SbGridCtl block the next launch reads (sb_physics.h; diagnostic: tools/grid_ctl_dump.py)
+        const int i = atoi(key + 9);
+        *value = 0;
+        if (e->d_grid_ctl && i >= 0 && i < (int)(sizeof(SbGridCtl) / 4)) {
+            uint32_t w = 0;
+            SB_HIP(e, hipStreamSynchronize(e->stream));
+            SB_HIP(e, hipMemcpy(&w, (const uint32_t *)(e->d_grid_ctl + e->grid_par) + i, 4, hipMemcpyDeviceToHost));
+            *value = w;
+        }
     }
     else if (k == "hybrid") *value = e->hy.K;                         // depth of the blocked plan beside the tiling (0: none, or not on the device yet)
     else if (k == "hybrid_substep_hbm_bytes") *value = e->hy.K ? blocked_bytes_model(e, e->hy) : 0; // of its blocked launches (k = hybrid_substeps_per_launch)

@@ -383,8 +383,14 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
         SB_STAMP(job.step, 5);
         // a substep that makes its lists: from the block thread 0 decided (behind the barrier that ends the beam phase);
         // otherwise the hash, its geometry and its age are those of the block this launch read
-        if (fresh) grid = sb_grid_view(grid_all, s_grid.now.cur, &s_grid.now.geo, s_grid.now.Cx, s_grid.now.Cy);
-        else grid = sb_grid_view(grid_all, s_grid.prev.cur, &s_grid.prev.geo, drift_Cx, drift_Cy);
+        // (everything uniform, and told so: the hash pointers are selected in scalar registers, not per lane)
+        const SbGridCtl &blk = fresh ? s_grid.now : s_grid.prev;
+        const uint32_t cur = __builtin_amdgcn_readfirstlane(blk.cur);
+        if (fresh) {
+            drift_Cx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_grid.now.Cx)));
+            drift_Cy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_grid.now.Cy)));
+        }
+        grid = sb_grid_view(grid_all, cur, &blk.geo, drift_Cx, drift_Cy);
     }
     // Phase 2: consume the complete force sums (compute.wgsl:171-201) -> WRITE state.
     bool any_acc = false;
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(SB_MT) void k_grid_build(SbGridStep t, uint32_t for
             SbGridCtl &N = s_grid.now; // (a copy of E so far: sb_grid_stage)
             N.fresh = 1u;
             N.need_build = N.pushing = N.abort = 0u;
-            N.settled = 1u;
+            N.settled = N.transient = 1u;
             N.cur = E.cur ^ 1u;
             N.builds = E.builds + 1u;
             N.since = 1u;

@@ -511,7 +511,7 @@ struct SbGridCtl {
     uint32_t cur;        // the hash buffer the lists in use came from
     uint32_t executed;   // substeps run since the upload (the host's roll-back after an abort counts on it)
     uint32_t builds;     // statistics: hashes built (or on order)
-    uint32_t since;      // substeps the lists in use have served, the coming one included
+    uint32_t since;      // age of the hash in use in substeps, the coming one included (what its bound `accum` has been collected over)
     float accum;         // D for the READ state of the coming substep
     float cx, cy;        // c for the coming substep
     float Cx, Cy;        // C for the READ state of the coming substep
@@ -522,7 +522,11 @@ struct SbGridCtl {
     uint32_t wide_next;  // 1: some build counted more than 1/64 of the particles outside its frame: the next one frames the whole domain
     uint32_t settled;    // 1: the displacement slots of the last substep are already in `accum` (or the lists were replaced since): the
                          // decision of the coming substep does not add them again (forced helper launch, k_grid_settle, the hybrid's write-back)
-    uint32_t pad_;
+    uint32_t transient;  // 1: hash `cur` came from a forced helper launch (upload, ghost refresh, recovery): how long it lasts says
+                         // nothing about the scene (a lattice relaxes its upload jitter in one big step) and does not move the skin
+    uint32_t short_lived; // 1: the last hash was replaced at an age of 6 substeps or less: the lagged schedule, which orders a hash one substep
+                         // early and spends another making lists, is the wrong one for this scene (a hint to the host: grid_substeps)
+    uint32_t pad_[3];
     SbGridGeom geo;      // hash `cur`
     SbGridGeom pgeo;     // hash cur ^ 1 while it is being pushed
 };
@@ -679,10 +683,14 @@ SB_DEV void sb_store_block_displacement(float4 *slots_out, float m)
 SB_DEV float sb_grid_next_skin(float skin, float skin_min, float skin_max, float accum, uint32_t since)
 {
     if (since <= 3u) {
-        // short-lived hash: a doubled skin must promise at least two substeps at the rate the bound has been
-        // growing, else the scene is simply too violent for any hash to last and lean cells are the cheapest
-        const float rate = accum / (float)since, wider = fminf(skin * 2.0f, skin_max);
-        if (wider >= 2.0f * rate) return wider;
+        // short-lived hash: a wider skin must promise at least two substeps at the rate the bound has been growing -- the
+        // smallest doubling that does (r03 tried one doubling only: a scene that speeds up while its skin is lean, 4 units
+        // against 4.4 per substep, then never gets off the minimum although 16 would last four substeps) -- else the scene is
+        // simply too violent for any hash to last and lean cells are the cheapest
+        const float rate = accum / (float)since;
+        for (float wider = skin * 2.0f; wider <= skin_max; wider *= 2.0f)
+            if (wider >= 2.0f * rate) return wider;
+        if (skin_max >= 2.0f * rate && skin_max > skin) return skin_max;
         if (!(skin >= 2.0f * rate)) return skin_min;
     } else if (since >= 64u) {
         return fmaxf(skin * 0.5f, skin_min);
@@ -826,21 +834,24 @@ SB_DEV void sb_grid_decide(const SbGridStep &t, const SbGrid &g, SbGridShared &s
         N.Cx = E.Cx + E.cx;
         N.Cy = E.Cy + E.cy;
         auto order = [&](SbGridGeom &out) { // the geometry of a hash to come (the skin adapts to how long this one lasted)
-            const float skin_new = sb_grid_next_skin(E.geo.skin, E.skin_min, E.skin_max, accum1, E.since);
+            const float skin_new = E.transient != 0u ? E.geo.skin : sb_grid_next_skin(E.geo.skin, E.skin_min, E.skin_max, accum1, E.since);
+            if (E.transient == 0u) N.short_lived = E.since <= 6u ? 1u : 0u;
             out = sb_grid_geom_for(g, skin_new, (E.geo.wide != 0u || wide_next != 0u) ? 1u : 0u);
             out.gen = E.builds + 1u;
             N.builds = E.builds + 1u;
             if (publish && blockIdx.x == 0u) SB_AGENT_STORE(&t.outside[(E.builds + 2u) & 3u], 0u);
         };
         if (E.pushing != 0u) { // lists from the hash the last substep pushed
+            N.transient = 0u;
             N.cur = E.cur ^ 1u;
             N.geo = E.pgeo;
-            N.since = 1u;
+            N.since = 2u; // (the age of the hash: the substep that pushed it is on its bound)
             N.accum = step;
             N.Cx = E.cx;
             N.Cy = E.cy;
         } else if (f.need_build != 0u) { // (classic: the helper builds hash cur ^ 1 with this geometry)
             order(N.geo);
+            N.transient = 0u;
             N.cur = E.cur ^ 1u;
             N.since = 1u;
             N.accum = N.Cx = N.Cy = 0.0f;
