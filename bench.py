@@ -549,6 +549,7 @@ def run_workload(ctx, a, W, H, subticks, mixed, mode, steps, warmup, named=None,
             torch.cuda.synchronize()
 
     timer = halo.StepTimer(eng)
+    timer.prepare(1 if ex is None else 2 * (steps // max(depth, 1) + 2))   # (event creation stays out of the timed region)
     if ex is None:
         eng.step(warmup)
     else:

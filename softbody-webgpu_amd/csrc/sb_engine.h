@@ -223,6 +223,7 @@ void sbk_launch_halo_unpack(sb_engine *e, const float *src);
 void sbk_launch_peer_exchange(sb_engine *e);
 // sb_blocked.hip
 void sbk_launch_blocked(sb_engine *e, uint32_t n, bool write_aux);
+void sbk_preload_blocked(const SbBlockedDev &bk, bool tracked); // resolve every kernel variant a call on this plan may launch (upload time)
 uint32_t sbk_split_call(uint32_t n, uint32_t kmax, bool fewest, uint32_t *first, uint32_t *n_first); // launches: n_first of depth first, the rest first - 1
 void sbk_launch_delete_blocked(sb_engine *e);
 void sbk_hybrid_to_blocked(sb_engine *e);

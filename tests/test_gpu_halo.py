@@ -70,6 +70,67 @@ def test_simulated_gpu_ranks_equal_single_engine(sb, world, depth, path, yield_s
     assert (want.particles[:, 1] == 10.0).any()
 
 
+@pytest.mark.parametrize("world,depth,yield_strain", [(2, 12, 0.2), (3, 16, 0.004)])
+def test_simulated_gpu_ranks_with_the_hash_on_run_blocked(sb, world, depth, yield_strain):
+    """The engine's DEFAULT collision mode on every rank (spatial hash; the reference always collides, compute.wgsl:142-170) on a
+    falling lattice in which nothing is within reach: between two ghost refreshes each rank runs blocked launches beside its
+    tiled layout -- until r04 an engine with ghost zones stayed on single substeps.  Every refresh orders a fresh
+    hash (ghosts jump), so a period is one single substep, a look, then tracked launches.  Owned particles and beams of the ranks
+    together = the single engine's, bit for bit; and the ranks did run blocked."""
+    import torch
+    from halo_oracle import LocalBus, step_all
+    halo = sb.halo
+    W, H = 36, 40
+    steps = 4 * depth + 5
+    kw = dict(d=30.0, origin=(100.0, 700.0), jitter=1.0, velocity=(0.3, -1.0), strain_limit=0.5, yield_strain=yield_strain)
+    bounds = 8000.0
+
+    def engine_for(buf):
+        e = sb.Engine(bounds_size=bounds, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=2,
+                      tile_particles=256)
+        e.write_buffers(buf)
+        return e
+
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    ref = engine_for(gbuf)
+    ref.step(steps)
+    want = ref.load_buffers(gbuf.copy())
+    assert ref.info("hybrid_substeps") > 0
+    ref.destroy()
+    dev = torch.device("cuda", 0)
+    bus = LocalBus()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng = engine_for(buf)
+        tr = bus.transport(r, lambda a, b: (torch.zeros(max(a, 1), device=dev), torch.zeros(max(b, 1), device=dev)),
+                           lambda t: t.data_ptr())
+        exs.append(halo.Exchanger(eng, plan, tr))
+        made.append((buf, plan, eng))
+
+    def sync():
+        for _, _, e in made:
+            e.sync()
+        torch.cuda.synchronize()
+
+    step_all(exs, bus, steps, lambda dst, src: dst.copy_(src), sync)
+    parts = np.zeros_like(want.particles)
+    beams = {}
+    blocked = []
+    for buf, plan, eng in made:
+        out = eng.load_buffers(buf.copy())
+        gid, prt, bkey, brec = halo.gather_owned(plan, out)
+        parts[gid] = prt
+        for k, rec in zip(bkey, brec):
+            beams[int(k)] = rec.tobytes()[8:]
+        blocked.append((eng.info("hybrid_substeps"), eng.info("substeps_done"), eng.info("hybrid_failed")))
+        eng.destroy()
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)] == rec.tobytes()[8:]
+    assert all(b[0] >= b[1] // 2 for b in blocked), blocked   # more than half of every rank's substeps ran in blocked launches
+
+
 @pytest.mark.parametrize("world,depth,path,block", [(2, 4, 2, 0), (3, 6, 2, 0), (2, 5, 2, 1), (2, 3, 1, 0)])
 def test_beams_that_break_across_simulated_gpu_ranks(sb, world, depth, path, block):
     """Frames with delete passes across ranks on the real kernels (blocked plan, single-substep tiling, atomic path): the
