@@ -193,6 +193,13 @@ def committed_traffic(workload, kernel, key="bench"):
     return best
 
 
+def newest_profile(suffix):
+    """Name of the newest committed profiles/rNN_<suffix> (the records are named per round)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)))
+    return os.path.basename(found[-1]) if found else "(none committed)"
+
+
 def committed_traffic_any(table_key, kernel):
     """HBM bytes per launch of `kernel` from table `table_key` of the newest committed summary (whatever workload that
     table was taken on: its name says), as (bytes, file) or None."""
@@ -310,12 +317,18 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
         share = blocked / done if done else 0.0
         own = share * hybrid_bytes + (1.0 - share) * own
     ach = own / per_substep_s / 1e9
-    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+    binding = "valu_issue" if (k > 1 or hybrid_bytes) else "hbm"
+    # `achieved` / `frac`: HBM bytes per second against the 8 TB/s peak -- from the MEASURED bytes of the committed PMC passes
+    # when there are any (then `achieved_model` / `frac_model` keep the engine's own byte model), else from the model.
+    # `bound` names the roof that binds this kernel: for the blocked kernel that is instruction issue
+    # (`valu_issue` below holds that fraction), and the HBM fraction says how far from the OTHER roof it runs.
+    roof = {"bound": binding, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "achieved_model": ach, "frac_model": ach / HBM_PEAK_GBS, "bytes": "model",
             "traffic": None,
             "kernel": eng.kernel_name() if tiled else "k_beams_atomic+k_particles",
             "substeps_per_launch": k, "avg_launch_us": per_substep_s * k * 1e6,
             "compulsory_bytes_per_launch": own * k,
-            "binding_roof": "valu_issue" if (k > 1 or hybrid_bytes) else "hbm",
+            "binding_roof": binding,
             "reference_layout_bytes_per_substep": 52.0 * B_local + 48.0 * P_local,
             "reference_layout_equiv_GBps": (52.0 * B_local + 48.0 * P_local) / per_substep_s / 1e9,
             "note": "achieved = compulsory bytes of the launched kernel (engine's own data layout: %d beam copies for %d "
@@ -340,6 +353,7 @@ def roofline(eng, kernel_ms, steps, P_local, B_local, workload):
         roof["traffic_over_compulsory"] = tr[0] / (own * k)
         roof["achieved_measured"] = tr[0] / (per_substep_s * k) / 1e9
         roof["frac_measured"] = roof["achieved_measured"] / HBM_PEAK_GBS
+        roof["achieved"], roof["frac"], roof["bytes"] = roof["achieved_measured"], roof["frac_measured"], "measured (PMC)"
     if k > 1:
         # the temporally blocked kernel is bound by instruction issue, not by HBM: the second roof it is
         # measured against.  1024 SIMDs issue one wave64 fp32 instruction per 2.8 cycles with four waves each (tools/valu_rate.hip)
@@ -441,11 +455,14 @@ def measure_config3(sb, a):
     eng.sync()
     settled = eng.load_buffers(buf.copy())              # what the CPU baseline below starts from, too
     builds0 = eng.info("grid_builds")
+    model_bytes = float(eng.info("substep_hbm_bytes"))
     eng.step(a.warmup)
     eng.sync()
+    sched0 = {k: eng.info(k) for k in ("grid_aborts", "grid_helper_launches", "grid_classic_substeps")}
     ms = eng.step_timed(a.steps)
     eng.sync()
     builds = eng.info("grid_builds") - builds0
+    schedule = {k: eng.info(k) - v for k, v in sched0.items()}
     steady = None
     if a.steady_steps > a.steps:                        # ... and at the step counts DESIGN.md quotes (never `value`)
         b0 = eng.info("grid_builds")
@@ -461,18 +478,29 @@ def measure_config3(sb, a):
            "steps": a.steps, "warmup": a.warmup, "grid_builds": builds, "upload_ms": upload_ms,
            "finite": bool(np.isfinite(out.particles[:P]).all()), "max_speed": float(v.max()),
            "beams_left": out.beam_count, "steady_state": steady,
+           "hash_schedule": dict(schedule, note="helper launches (k_grid_build) and substeps of the classic schedule inside the timed region: "
+                                                 "0 / 0 = every hash was pushed by the substep kernels themselves (lagged schedule, DESIGN 4.4)"),
            "contacts": "tools/config3_contacts_check.py measures the share of particles the collision loop changes "
-                       "(profiles/r02_config3_contacts_check.txt)"}
+                       "(profiles/%s)" % newest_profile("config3_contacts_check.txt")}
     # measured HBM bytes per substep of the two kernels of this scene, from the committed PMC passes of `bench.py --config3`
-    tr = [committed_traffic_any("traffic_config3", k) for k in ("k_substep_tiled_grid", "k_grid_maintain")]
-    if all(tr):
-        per_substep = tr[0][0] + tr[1][0]
-        rec["hbm"] = {"traffic_bytes_per_substep": per_substep, "achieved_GBps": per_substep / (ms * 1e-3 / a.steps) / 1e9,
-                      "frac_of_peak": per_substep / (ms * 1e-3 / a.steps) / 1e9 / HBM_PEAK_GBS,
-                      "source": "profiles/%s traffic_config3 (k_substep_tiled_grid + k_grid_maintain, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % tr[0][1],
-                      "note": "neighbour lists and position gathers included; %.0f MB per launch of the substep kernel, %.1f MB per "
-                              "launch of the hash helper (averages over the launches of the profiled run)"
-                              % (tr[0][0] / 1e6, tr[1][0] / 1e6)}
+    # its own roofline object (HBM-bound: one substep per launch).  Bytes: the PMC passes of `bench.py --config3` committed under
+    # profiles/ (since r04 the substep kernel is the only launch of a substep: the hash's helper launch is gone, sb_physics.h
+    # SbGridCtl); the engine's byte model (beams, particles, halo: no neighbour lists) beside it.
+    per = ms * 1e-3 / a.steps
+    tr = committed_traffic_any("traffic_config3", "k_substep_tiled_grid")
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "k_substep_tiled_grid", "substeps_per_launch": 1,
+            "avg_launch_us": per * 1e6, "achieved_model": model_bytes / per / 1e9, "frac_model": model_bytes / per / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "binding_roof": "hbm",
+            "model_note": "the engine's byte model prices beam copies, particles and halo entries; the neighbour-list walks of this scene "
+                          "(list lengths, entries, the positions and velocities they gather) come on top: the measured bytes are the larger"}
+    if tr:
+        roof.update({"traffic": tr[0], "achieved": tr[0] / per / 1e9, "frac": tr[0] / per / 1e9 / HBM_PEAK_GBS, "bytes": "measured (PMC)",
+                     "achieved_measured": tr[0] / per / 1e9, "frac_measured": tr[0] / per / 1e9 / HBM_PEAK_GBS,
+                     "traffic_source": "profiles/%s traffic_config3 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --config3; "
+                                       "neighbour lists and position gathers included, average over the launches of the profiled run)" % tr[1]})
+    else:
+        roof.update({"achieved": roof["achieved_model"], "frac": roof["frac_model"], "bytes": "model"})
+    rec["roofline"] = roof
     if not a.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline_config3(sb, settled, bounds, a.cpu_seconds)
     return rec
@@ -597,6 +625,12 @@ def run_workload(ctx, a, W, H, subticks, mixed, mode, steps, warmup, named=None,
            "grid_builds": eng.info("grid_builds") if mode == 2 else None, "upload_ms": upload_ms,
            "kernel_us_per_substep": kernel_ms * 1e3 / steps,
            "roofline": roofline(eng, kernel_ms, steps, P_local, B_local, workload) if kernel_ms > 0 else None}
+    if mode == 2:
+        rec["hybrid"] = {"substeps_in_blocked_launches": eng.info("hybrid_substeps"), "substeps": eng.info("substeps_done"),
+                         "launches_refused": eng.info("hybrid_failed"), "grid_aborts": eng.info("grid_aborts"),
+                         "helper_launches": eng.info("grid_helper_launches"),
+                         "note": "rank 0, since the upload (warm-up included): substeps that ran in tracked blocked launches beside the tiled "
+                                 "layout (DESIGN 4.1b; engines with ghost zones too since r04)"}
     if world == 1:
         rec["parallelism"] = "single GPU"
     else:
@@ -717,6 +751,12 @@ def main():
                 if plain:
                     extra["config3"] = measure_config3(sb, a)
             del buf
+            if plain and mode == 0 and world > 1:
+                # the main scene once more with the engine's DEFAULT collision mode on every rank (the reference always collides):
+                # what extra.default_collision_mode is at N = 1
+                r = run_workload(ctx, a, a.width, a.height, a.subticks, False, 2, a.steps, a.warmup, want_cpu=False)
+                r.pop("_buf"), r.pop("_bounds")
+                extra["default_collision_mode"] = r
             if plain and mode == 0:
                 # BASELINE configs 4 and 5 in the same run: at N GPUs, N slabs of each (at 8 GPUs these ARE configs 4 and 5;
                 # below that, N GPUs' share of them), same step counts, their own exchanges, a short CPU baseline
