@@ -112,3 +112,77 @@ def test_config5_one_rank_at_share_size(sb, oracle):
     p = tiled.particles[:buf.particle_count]
     assert np.isfinite(p).all() and (p[:, :2] >= 10.0).all() and (p[:, :2] <= bounds - 10.0).all()
     assert np.abs(p[:, 2:4]).max() < 50.0 and not np.array_equal(p, buf.particles[:buf.particle_count])
+
+
+@pytest.mark.parametrize("name,W,H,subticks,mixed", [("config 4: the WHOLE 8-slab partition, 16 M particles", 500, 4000, 64, False),
+                                                       ("config 5's partition at an eighth of its height (1000 x 1000 per slab, 8 M)", 1000, 1000, 128, True)])
+def test_whole_eight_slab_partition_on_one_gpu(sb, name, W, H, subticks, mixed):
+    """VERDICT r03 #2a: not two of eight slabs but all eight -- interior ranks with two neighbours, both edge ranks -- as eight
+    engines on the one GPU of a gpurun box, ghost zones 24 columns deep, refreshed through device copies (the real pack / unpack
+    kernels; more than three engines of one process cannot be wired by sb_peer_*: HIP's four hardware queues), against ONE engine
+    that holds the whole lattice: 2 refresh periods + 5 substeps, owned particles and owned beams bit for bit.  Config 5 at its
+    full 64 M particles does not fit the time a test may take (its 8000 rows only lengthen the columns: the partition, the
+    ghost lists and the exchange are those of this test); one rank's full-height slab is test_config5_one_rank_at_share_size."""
+    import torch
+    from halo_oracle import LocalBus, step_all
+    halo = sb.halo
+    world, depth = 8, 24
+    steps = 2 * depth + 5
+    bounds = float(max(W * world, H) * 30.0 + 2000.0)
+    kw = dict(d=30.0, origin=(1000.0, 1000.0), jitter=1.0)
+
+    def prepared(buf, plan):
+        if mixed:
+            halo.mix_stiffness(buf, plan, subticks=subticks)   # keyed by the global beam key: ghosts match their owners
+        return buf
+
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    prepared(gbuf, gplan)
+    assert gbuf.particle_count == world * W * H
+    whole = engine(sb, gbuf, bounds, subticks=subticks)
+    whole.step(steps)
+    want = whole.load_buffers(gbuf.copy())
+    whole.destroy()
+    order = np.argsort(gplan.global_beam_key, kind="stable")
+    keys_sorted = gplan.global_beam_key[order]
+
+    dev = torch.device("cuda", 0)
+    bus = LocalBus()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        prepared(buf, plan)
+        assert len(plan.peers) == (1 if r in (0, world - 1) else 2)
+        eng = engine(sb, buf, bounds, subticks=subticks)
+        tr = bus.transport(r, lambda a, b: (torch.zeros(max(a, 1), device=dev), torch.zeros(max(b, 1), device=dev)),
+                           lambda t: t.data_ptr())
+        exs.append(halo.Exchanger(eng, plan, tr))
+        made.append((buf, plan, eng))
+
+    def sync():
+        for _, _, e in made:
+            e.sync()
+        torch.cuda.synchronize()
+
+    step_all(exs, bus, steps, lambda dst, src: dst.copy_(src), sync)
+    parts = np.zeros_like(want.particles)
+    seen_p = np.zeros(want.particles.shape[0], bool)
+    seen_b = np.zeros(want.beams.shape[0], bool)
+    fields = [f for f in want.beams.dtype.names if f not in ("a", "b", "pair")]
+    for buf, plan, eng in made:
+        out = eng.load_buffers(buf.copy())
+        eng.destroy()
+        gid, prt, bkey, brec = halo.gather_owned(plan, out)
+        parts[gid] = prt
+        assert not seen_p[gid].any()
+        seen_p[gid] = True
+        at = order[np.searchsorted(keys_sorted, bkey)]
+        assert np.array_equal(gplan.global_beam_key[at], bkey) and not seen_b[at].any()
+        seen_b[at] = True
+        for f in fields:   # (everything but the endpoint indices, which are local to a rank's scene)
+            assert np.array_equal(brec[f].view("u4"), want.beams[f][at].view("u4")), (name, f)
+        del out
+    P, B = gbuf.particle_count, gbuf.beam_count
+    assert seen_p[:P].all() and seen_b[:B].all()                       # every particle and every beam has exactly one owner
+    assert np.array_equal(parts[:P].view("u4"), want.particles[:P].view("u4")), name
+    assert np.isfinite(parts[:P]).all() and not np.array_equal(parts[:P], gbuf.particles[:P])
