@@ -92,13 +92,16 @@ typedef struct sb_options {
     uint32_t layout;         /* SB_LAYOUT_* */
     uint32_t collision_mode; /* SB_COLLIDE_* */
     uint32_t path;           /* SB_PATH_* */
-    uint32_t tile_particles; /* SB_PATH_TILED: target particles per tile (0 = default) */
+    uint32_t tile_particles; /* SB_PATH_TILED: target particles per tile (0 = the engine picks: fewest rounds of resident tiles).
+                              * An UPPER BOUND where several substeps run per launch (collisions off, or nothing within reach): a tile of
+                              * that kernel owns at most 1024 particles and 3072 beams, larger targets are lowered to fit */
     int32_t device_ordinal;  /* HIP device */
     float grid_skin;         /* SB_COLLIDE_GRID: cells are 2r + 2*skin wide and the hash is rebuilt only when
                               * some particle may have moved more than `skin` (relative to the scene's common
-                              * drift) since the last build.  0 = default: adaptive, starting at 0.4 r and
-                              * doubling up to 1.6 r while hashes last 2 substeps or less; > 0 = that skin,
-                              * fixed; negative = rebuild every substep */
+                              * drift) since the last build.  0 = default: adaptive, starting at 0.4 r; a hash that
+                              * is worn out within 3 substeps is followed by one with the smallest doubled skin (up
+                              * to 1.6 r) that promises two substeps, one that lasted 64 by one half as wide; > 0 =
+                              * that skin, fixed; negative = rebuild every substep */
     uint32_t block_substeps; /* SB_PATH_TILED: substeps one launch advances out of LDS and registers (temporal
                               * blocking over beam-hop rings; same bits as single substeps).  With SB_COLLIDE_OFF
                               * always; with SB_COLLIDE_GRID for the stretches of a run in which every neighbour

@@ -863,7 +863,11 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     reap_join(e);
     {
         bool kept = false;
-        SB_TRY(rewrite_scene_state(e, md, mp, pd, bd, &kept));
+        const sb_status st = rewrite_scene_state(e, md, mp, pd, bd, &kept);
+        if (st != SB_OK) { // (past its point of no return the device holds half of each scene: nothing may step or read it)
+            e->loaded = false;
+            return st;
+        }
         if (kept) return SB_OK;
     }
     free_scene(e);
@@ -987,9 +991,10 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             };
             blockK = std::min<uint32_t>(e->opt.block_substeps ? e->opt.block_substeps : SB_BK_KPLAN, SB_BK_KMAX);
             sb_build_blocking(bl, px, py, hb, target, blockK);
-            if (!e->opt.tile_particles && (bl.max_own > SB_BK_OWNP * SB_BK_T || bl.max_ownb > SB_BK_OWNB * SB_BK_T)) {
-                // the automatic tile size owns more than the kernel's own slots hold (a scene with four or more beams per
-                // particle): smaller tiles, once
+            if (bl.max_own > SB_BK_OWNP * SB_BK_T || bl.max_ownb > SB_BK_OWNB * SB_BK_T) {
+                // the tile size owns more than the kernel's own slots hold (the automatic one on a scene with four or more beams
+                // per particle; an explicit sb_options.tile_particles above 1024 -- it is an upper bound, include/softbody.h:
+                // until r04 such a value silently lost the blocked kernel): smaller tiles, once
                 const double shrink = std::min((double)(SB_BK_OWNP * SB_BK_T) / bl.max_own, (double)(SB_BK_OWNB * SB_BK_T) / std::max(bl.max_ownb, 1u));
                 target = std::max<uint32_t>(128u, (uint32_t)(target * shrink * 0.97));
                 sb_build_blocking(bl, px, py, hb, target, blockK);
@@ -1468,7 +1473,7 @@ static sb_status hybrid_materialise(sb_engine *e)
     if (hk && hbl.order == e->h_pslot && hbl.tile_p0 == e->h_tile_p0) {
         SbStageTimer tm;
         st = upload_blocked(e, hbl, e->h_beams, hk, tm, true, &e->h_copy_of_slot, &e->h_slot_of_copy);
-        if (st == SB_OK && !hk) e->hy = SbBlockedDev{};
+        if (st != SB_OK || !hk) e->hy = SbBlockedDev{}; // (a plan that is not whole is no plan: the engine stays on single substeps)
         tm.mark("blocked plan beside the tiling");
     }
     delete p;

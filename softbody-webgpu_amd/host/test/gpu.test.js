@@ -25,6 +25,21 @@ const rd = (f) => { const b = fs.readFileSync(path.join(GOLDEN, f)); return b.bu
     for (let i = 0; i < got.length; i++) if (got[i] !== want[i]) diff++;
     assert.strictEqual(diff, 0, diff + ' bytes differ from the oracle golden');
 
+    // N4, on GPU-produced state (VERDICT r03): the picture render.wgsl:33-89 draws -- discs with a white ring, beams coloured by
+    // the device's stress / strain outputs -- of the state the GPU frames left, against the picture of the oracle's state
+    const picture = (snapshot) => {
+        const m = new h.BufferMapper(1 << 22, { layout: 1 });
+        assert.strictEqual(m.loadSnapshotbuffer(snapshot), true);
+        return h.renderPPM(m, { resolution: 500 });
+    };
+    const ppmGpu = picture(snap), ppmOracle = picture(rd('default_scene_v1_after_2_frames.snapshot'));
+    assert.ok(ppmGpu.equals(ppmOracle), 'the render of the GPU state differs from the render of the oracle state');
+    const ppmStart = picture(rd('default_scene_v1.snapshot'));
+    assert.ok(!ppmGpu.equals(ppmStart), 'two frames must have moved the picture');
+    let coloured = 0; // beams under load are not white / plain green: some pixel has a red channel between the extremes
+    for (let i = 15; i + 2 < ppmGpu.length; i += 3) if (ppmGpu[i] > 0 && ppmGpu[i] < 255 && ppmGpu[i + 2] !== ppmGpu[i]) coloured++;
+    assert.ok(coloured > 50, 'stress-coloured beam pixels: ' + coloured);
+
     // wide layout + tiled path through the worker API directly, 1000 substeps (BASELINE config 1 shape)
     const w = new h.WGPUSoftbodyEngineWorker(null, { layout: 2, maxParticles: 2048, maxBeams: 8192, collisionMode: h.COLLIDE.OFF,
         path: h.PATH.TILED, tileParticles: 256 });
@@ -49,5 +64,5 @@ const rd = (f) => { const b = fs.readFileSync(path.join(GOLDEN, f)); return b.bu
     await w.destroy();
     await engine.destroy();
     assert.strictEqual(engine.destroyed, true);
-    console.log(JSON.stringify({ ok: true, frames: 2, substeps1000_ms: ms, info }));
+    console.log(JSON.stringify({ ok: true, frames: 2, substeps1000_ms: ms, info, renderedBytes: ppmGpu.length, colouredPixels: coloured }));
 })().catch((e) => { console.error(e); process.exit(1); });

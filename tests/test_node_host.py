@@ -38,6 +38,7 @@ def test_js_host_gpu_end_to_end():
     1000 substeps of the config-1 lattice through the worker API."""
     r = run_node("gpu.test.js")
     assert r["ok"] and r["info"]["path"] == 2 and r["info"]["tiles"] >= 4
+    assert r["renderedBytes"] > 500 * 500 * 3 and r["colouredPixels"] > 50      # N4: the GPU state rendered, equal to the oracle state's picture
 
 
 @needs_node
