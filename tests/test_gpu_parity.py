@@ -14,10 +14,10 @@ OFF, ALLPAIRS, GRID = 0, 1, 2
 
 
 def run_both(sb, oracle, buf, *, n=None, frames=0, path=0, mode=ALLPAIRS, bounds=1000.0, radius=10.0,
-             subticks=64, tile=0, before=None, ref_mode=None):
+             subticks=64, tile=0, before=None, ref_mode=None, block=0):
     eng = sb.Engine(bounds_size=bounds, particle_radius=radius, subticks=subticks, layout=buf.layout,
                     max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=mode,
-                    path=path, tile_particles=tile)
+                    path=path, tile_particles=tile, block_substeps=block)
     ref = oracle.OracleEngine(bounds, radius, subticks, buf.layout, mode if ref_mode is None else ref_mode,
                               threads=8)
     eng.write_buffers(buf)
@@ -553,12 +553,32 @@ def test_reupload_replaces_everything(sb, oracle, mode):
 
 @pytest.mark.parametrize("tile,mode", [(3000, OFF), (2500, GRID)])
 def test_tiles_larger_than_the_prefetch_window(sb, oracle, tile, mode):
-    """Tiles above 2 x 512 particles take the tail loops of k_substep_tiled (phase 0, phase 2, grid ranges)."""
+    """Tiles above 2 x 512 particles take the tail loops of k_substep_tiled (phase 0, phase 2, grid ranges).  (One substep per
+    launch asked for: where several run per launch a tile size is an upper bound and is lowered to the blocked kernel's own
+    slots -- test_explicit_tile_size_above_the_blocked_kernels_slots_is_lowered.)"""
     buf = sb.scenes.lattice_buffers(80, 75, d=30.0, origin=(60.0, 12.0), jitter=1.0, layout=2, velocity=(0.5, -3.0))
-    got, exp, info = run_both(sb, oracle, buf, n=150, mode=mode, path=TILED, bounds=4000.0, tile=tile)
+    got, exp, info = run_both(sb, oracle, buf, n=150, mode=mode, path=TILED, bounds=4000.0, tile=tile, block=1)
     assert info["tiles"] in (2, 3)
     assert_same(got, exp, "tile %d" % tile)
     assert (got.particles[:, 1] == 10.0).any()
+
+
+def test_explicit_tile_size_above_the_blocked_kernels_slots_is_lowered(sb, oracle):
+    """sb_options.tile_particles = 3000 with collisions off: until r04 no depth of the blocked plan fitted such tiles (its kernel
+    owns at most 1024 particles and 3072 beams per tile) and the engine silently dropped to one substep per launch (ADVICE r03);
+    now the size is an upper bound: smaller tiles, the blocked kernel, the oracle's bits."""
+    buf = sb.scenes.lattice_buffers(80, 75, d=30.0, origin=(60.0, 12.0), jitter=1.0, layout=2, velocity=(0.5, -3.0))
+    eng = sb.Engine(bounds_size=4000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=OFF, path=TILED,
+                    tile_particles=3000)
+    ref = oracle.OracleEngine(4000.0, 10.0, 64, 2, OFF, threads=8)
+    eng.write_buffers(buf)
+    ref.write_buffers(buf)
+    assert eng.info("substeps_per_launch") > 1 and eng.info("tiles") >= 6
+    eng.step(150)
+    ref.step(150)
+    got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+    eng.destroy()
+    assert_same(got, exp, "tile 3000 lowered")
 
 
 @pytest.mark.parametrize("subticks", [100, 36])
