@@ -451,8 +451,8 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     for (int i = 0; i < SB_BK_OWNP; i++) {
         const uint32_t q = tid_s + (uint32_t)i * SB_BK_T;
         if (q < n_own) {
-            w.pos[p0 + q] = s_pos[q];
-            w.vel[p0 + q] = pv[i];
+            sb_store_wt(&w.pos[p0 + q], s_pos[q]); // (write-through: sb_physics.h; config 2 at 1 M: 8.15 -> 8.32e10)
+            sb_store_wt(&w.vel[p0 + q], pv[i]);
             const bool nz = (__float_as_uint(pa[i].x) | __float_as_uint(pa[i].y)) != 0u; // -0.0 counts
             any_acc |= nz;
             if (nz || acc_w_dirty) w.acc[p0 + q] = pa[i];
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         const uint32_t j = tid_s + (uint32_t)i * SB_BK_T;
         if (j < n_ownb) {
             if (__builtin_expect(word[i] != bp.dummy_word, 1)) {
-                if (plastic_w) bs.target_w[b0 + j] = tg[i];
-                bs.last_w[b0 + j] = ls[i];
+                if (plastic_w) sb_store_wt(&bs.target_w[b0 + j], tg[i]);
+                sb_store_wt(&bs.last_w[b0 + j], ls[i]);
                 if ((brk >> i) & 1u) {
                     atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
                     if (TRACK) __hip_atomic_store(tr.any_broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -353,7 +353,7 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
 #endif
                 // target_length only moves on plastic yield (compute.wgsl:113-116): store it when it did
                 if (__float_as_uint(res.target_length) != __float_as_uint(target)) b.target[c] = res.target_length;
-                b.last[c] = res.last_length;
+                sb_store_wt(&b.last[c], res.last_length);
                 if (AUX) { // strain/stress: outputs only (:122-123), stored by the last substep of a call
                     b.strain[c] = res.strain;
                     b.stress[c] = res.stress;
@@ -422,8 +422,8 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
             moved = fmaxf(moved, fmaxf(sb_abs(dx - drift_x), sb_abs(dy - drift_y)) * 1.4142137f);
             if (i == 0u) sb_store_sample_displacement(job.step.slots_out, dx, dy); // i == 0 is thread 0's first particle
         }
-        w.pos[g] = particle.p;
-        w.vel[g] = particle.v;
+        sb_store_wt(&w.pos[g], particle.p); // (write-through: sb_physics.h)
+        sb_store_wt(&w.vel[g], particle.v);
         const bool nz = (__float_as_uint(particle.a.x) | __float_as_uint(particle.a.y)) != 0u; // -0.0 counts
         any_acc |= nz;
         if (nz || acc_w_dirty) w.acc[g] = particle.a;
