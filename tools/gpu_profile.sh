@@ -4,7 +4,7 @@
 # (the three parts fit one 20-minute gpurun call each; "all" is for a box without that limit)
 # Every rocprofv3 run has the program itself after `--`; --pmc passes carry --kernel-trace only.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}
 OUT=$PWD/gpurun_out/$TAG
 ROOT=$PWD
@@ -62,6 +62,11 @@ python3 bench.py --no-cpu-baseline --no-extra --width 4000 --height 4000 --steps
 python3 tools/exchange_cost.py 2>/dev/null | grep "^depth" > $OUT/exchange_cost.txt || echo "exchange cost probe failed"
 python3 bench.py --gpus 2 --rehearse-one-gpu --steps 480 --warmup 48 2>/dev/null > $OUT/rehearse_2ranks.json || echo "rehearsal failed"
 python3 bench.py --gpus 2 --rehearse-one-gpu --steps 20 --warmup 5 2>/dev/null > $OUT/rehearse_2ranks_driver_protocol.json || echo "rehearsal (driver protocol) failed"
+# ... the same two ranks with the engine's default collision mode (hash on: blocked launches between the ghost refreshes since r04)
+python3 bench.py --gpus 2 --rehearse-one-gpu --collisions grid --steps 480 --warmup 48 --no-cpu-baseline --no-extra 2>/dev/null > $OUT/rehearse_2ranks_grid.json || echo "rehearsal (grid) failed"
+# the spatial hash's two schedules on the config-3 scenes (lagged by default, classic forced)
+python3 tools/grid_schedule_probe.py 2>/dev/null | grep us/substep > $OUT/grid_schedule_probe.txt || echo "schedule probe failed"
+SB_GRID_MODE=classic python3 tools/grid_schedule_probe.py 2>/dev/null | grep us/substep >> $OUT/grid_schedule_probe.txt || echo "schedule probe (classic) failed"
 node softbody-webgpu_amd/host/bench.js > $OUT/node_bench.json 2> $OUT/node_bench.err || echo "node bench failed"
 SB_UPLOAD_TIMING=1 python3 tools/upload_timing.py 2>&1 | grep -v "amdgpu.ids" > $OUT/upload_timing.txt || echo "upload timing failed"
 fi

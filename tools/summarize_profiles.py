@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 if not os.path.isdir(src) or not glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
@@ -72,7 +72,8 @@ for name, out in (("bench_config3.json", "%s_bench_config3.json"), ("bench_singl
                   ("bench_soup.json", "%s_bench_soup.json"), ("config3_contacts_check.txt", "%s_config3_contacts_check.txt"),
                   ("bench_grid_no_hybrid.json", "%s_bench_grid_no_hybrid.json"), ("bench_driver_protocol.json", "%s_bench_driver_protocol.json"),
                   ("bench_rest_lengths.json", "%s_bench_rest_lengths.json"),
-                  ("rehearse_2ranks_driver_protocol.json", "%s_rehearse_2ranks_one_gpu_driver_protocol.json")):
+                  ("rehearse_2ranks_driver_protocol.json", "%s_rehearse_2ranks_one_gpu_driver_protocol.json"),
+                  ("rehearse_2ranks_grid.json", "%s_rehearse_2ranks_one_gpu_grid.json"), ("grid_schedule_probe.txt", "%s_grid_schedule_probe.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, out % tag))
@@ -110,7 +111,7 @@ def traffic_of(suffix):
 traffic = traffic_of("")
 summary["traffic"] = traffic
 summary["traffic_bench_single_substep"] = traffic_of("_k1")   # k_substep_tiled, --block-substeps 1
-summary["traffic_config3"] = traffic_of("_cfg3")   # k_substep_tiled_grid and k_grid_maintain on the settled blob pile
+summary["traffic_config3"] = traffic_of("_cfg3")   # k_substep_tiled_grid on the settled blob pile (until r03 also the helper launch k_grid_maintain)
 sq = {}
 for which in ("pmc_sq1", "pmc_sq2"):
     for (k, c), (n, avg) in counters(one(which + "/*/*_counter_collection.csv")).items():
