@@ -1068,6 +1068,17 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         SB_TRY(dev_alloc(e, &e->d_pslot, P));
         SB_TRY(stage_put_bytes(e, e->d_pidx, e->h_pidx.data(), (size_t)P * 4));
         SB_TRY(stage_put_bytes(e, e->d_pslot, e->h_pslot.data(), (size_t)P * 4));
+        e->d_islot = nullptr;
+        if (e->opt.collision_mode == SB_COLLIDE_GRID && e->path == SB_PATH_TILED) { // (active slots are 0 .. P - 1)
+            SB_TRY(dev_alloc(e, &e->d_islot, P));
+            SB_TRY(stage_put(e, e->d_islot, (size_t)P * 4, [&](size_t off, size_t len, uint8_t *out) {
+                uint32_t *o = (uint32_t *)out;
+                const size_t first = off / 4, n = len / 4;
+                sbt::parallel_ranges(n, 1 << 16, [&](size_t i0, size_t i1) {
+                    for (size_t i = i0; i < i1; i++) o[i] = internal_of_slot[first + i];
+                });
+            }));
+        }
     }
 
     tm.mark("particles to device");
@@ -1135,6 +1146,18 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->lds_bytes = (size_t)tl.max_all * sizeof(float2) + (size_t)tl.max_all * sizeof(int2) + (size_t)e->nmat * 6 * sizeof(float);
         if (e->lds_bytes > 160 * 1024)
             SB_FAIL(e, SB_ERR_UNSUPPORTED, "tile needs %zu bytes of LDS (> 160 KiB): lower tile_particles or use SB_PATH_ATOMIC", e->lds_bytes);
+        // SB_COLLIDE_GRID: what is left of a quarter of the CU's LDS (four workgroups per CU) behind the kernel's own arrays is
+        // the area the workgroup makes its tile's neighbour lists in (sb_lists_cooperative: 12 bytes per record and cell)
+        e->lds_coop_off = e->lds_coop = 0;
+        if (e->opt.collision_mode == SB_COLLIDE_GRID) {
+            static const bool coop_off = [] { const char *v = getenv("SB_GRID_COOP"); return v && atoi(v) == 0; }();
+            const size_t quarter = 160 * 1024 / 4, fixed = 1024 /* the kernel's static LDS */ + 512 /* allocation granule */;
+            const size_t off = (e->lds_bytes + 15) & ~(size_t)15;
+            if (!coop_off && off + fixed + 8 * 1024 <= quarter) {
+                e->lds_coop_off = (uint32_t)off;
+                e->lds_coop = (uint32_t)((quarter - fixed - off) & ~(size_t)15);
+            }
+        }
     } else {
         c_ia.resize(B);
         c_ib.resize(B);
@@ -1957,7 +1980,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k.rfind("grid_stamp_", 0) == 0) { // -DSB_STAMPS builds: stamps of one mid-grid workgroup of the last substep launch, 10 ns ticks since its start (diagnostic)
         const int i = atoi(key + 11);
         SB_HIP(e, hipStreamSynchronize(e->stream));
-        *value = (i >= 0 && i < 7 && e->dev_err) ? e->dev_err[4 + i] : 0;
+        *value = (i >= 0 && i < 40 && e->dev_err) ? e->dev_err[4 + i] : 0; // (i >= 16: the last launch that made its lists together)
     }
     else if (k.rfind("grid_ctl_", 0) == 0) { // word <n> of the SbGridCtl block the next launch reads (sb_physics.h; diagnostic: tools/grid_ctl_dump.py)
         const int i = atoi(key + 9);

@@ -137,6 +137,8 @@ struct sb_engine {
                                    // scalar-cache lines are not reliably refreshed between launches on this stack
     uint32_t *d_pidx = nullptr;    // data index per internal particle (collision tie-break :153)
     uint32_t *d_pslot = nullptr;
+    uint32_t *d_islot = nullptr;   // internal particle per slot (SB_COLLIDE_GRID on the tiled path: sb_lists_cooperative)
+    uint32_t lds_coop_off = 0, lds_coop = 0; // ... and that function's area behind the substep kernel's own dynamic LDS (bytes; 0: none)
     int2 *d_forces = nullptr;      // atomic path accumulator (compute.wgsl:68-69)
     uint32_t *d_broken = nullptr;  // bit per beam copy: flagged this frame (compute.wgsl:86-88)
     uint32_t *d_dead_gen = nullptr;  // per beam slot: number of the delete pass that removed it (0 = live)

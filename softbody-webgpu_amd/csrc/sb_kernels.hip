@@ -276,14 +276,21 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
         const SbGridGeom pg = sb_grid_geom_load(&s_grid.now.pgeo);
         const uint32_t buf = __builtin_amdgcn_readfirstlane(s_grid.now.cur) ^ 1u;
         uint32_t n_out = 0u;
+        // (two particles per thread side by side: both returning exchanges in flight before either record needs its answer)
 #pragma unroll 1
-        for (uint32_t i = tid; i < n_own; i += SB_TILE_BLOCK) {
-            const float2 p = s_pos[i];
-            uint32_t cell;
-            bool o = false;
-            const unsigned long long old = sb_grid_push_begin(job.build, buf, pg, p0 + i, p, &cell, &o);
-            n_out += o ? 1u : 0u;
-            sb_grid_push_end(job.build, buf, pg, p0 + i, p, job.pslot[p0 + i], cell, old);
+        for (uint32_t i0 = tid; i0 < n_own; i0 += 2u * SB_TILE_BLOCK) {
+            const uint32_t i1 = i0 + SB_TILE_BLOCK;
+            const bool two = i1 < n_own;
+            const float2 pa0 = s_pos[i0], pa1 = s_pos[two ? i1 : i0];
+            const uint32_t sl0 = job.pslot[p0 + i0], sl1 = job.pslot[p0 + (two ? i1 : i0)];
+            uint32_t c0, c1 = 0u;
+            bool o0 = false, o1 = false;
+            const unsigned long long old0 = sb_grid_push_begin(job.build, buf, pg, p0 + i0, pa0, &c0, &o0);
+            unsigned long long old1 = 0ull;
+            if (two) old1 = sb_grid_push_begin(job.build, buf, pg, p0 + i1, pa1, &c1, &o1);
+            n_out += (o0 ? 1u : 0u) + (o1 ? 1u : 0u);
+            sb_grid_push_end(job.build, buf, pg, p0 + i0, pa0, sl0, c0, old0);
+            if (two) sb_grid_push_end(job.build, buf, pg, p0 + i1, pa1, sl1, c1, old1);
         }
         sb_grid_count_outside(&job.build.outside[pg.gen & 3u], n_out);
     }
@@ -428,6 +435,26 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
         any_acc |= nz;
         if (nz || acc_w_dirty) w.acc[g] = particle.a;
     };
+    // A substep that makes its lists: the whole tile's, by the workgroup together through LDS (sb_lists_cooperative) -- after which
+    // it is a substep like any other, walked by the main pass below with the lengths just written.  A tile whose particles have
+    // scattered beyond what the LDS area holds has every particle walk the hash for itself in the second pass instead.
+    if (MODE == SB_COLLIDE_GRID && fresh && job.coop_bytes != 0u) {
+        const SbGridGeom gm = sb_grid_geom_load(grid.geo);
+        SB_STAMP(job.step, 8);
+        if (sb_lists_cooperative(grid, gm, p0, n_own, job.pslot, job.islot, sb_lds + job.coop_off, job.coop_bytes
+#ifdef SB_STAMPS
+                                 , job.step, sb_t_start
+#endif
+                                 )) { // (uniform)
+            fresh = false;
+#pragma unroll
+            for (int u = 0; u < SB_UNROLL; u++) {
+                const uint32_t i = tid + (uint32_t)u * SB_TILE_BLOCK;
+                ncand[u] = i < n_own ? grid.nl_count[p0 + i] : 0u; // (written by this very thread)
+            }
+            SB_STAMP(job.step, 9);
+        }
+    }
     // main pass: every particle whose list can simply be walked (all of them, on almost every substep)
     bool any_slow = false;
     if (!fresh) {
@@ -446,8 +473,10 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
             else finish(i, r.vel[p0 + i], acc_r ? r.acc[p0 + i] : make_float2(0.f, 0.f), count, std::false_type{});
         }
     }
-    // second pass, SB_COLLIDE_GRID only: the substep after a hash build (every particle makes its list), or the
+    // second pass, SB_COLLIDE_GRID only: the substep after a hash build (every particle's list is made first), or the
     // particles of piles that overflow their lists
+    // second pass, SB_COLLIDE_GRID only: the substep after a hash build where the tile could not make its lists together (every
+    // particle makes its own first), or the particles of piles that overflow their lists
     if (MODE == SB_COLLIDE_GRID && (fresh || __syncthreads_or(any_slow ? 1 : 0))) {
 #pragma unroll 1
         for (uint32_t i = tid; i < n_own; i += SB_TILE_BLOCK) {
@@ -461,6 +490,12 @@ __device__ __forceinline__ void sb_substep_tiled(SB_TILED_PARAMS)
     const int wg_any = __syncthreads_or(any_acc ? 1 : 0);
     if (tid == 0) acc_flag_w[tile] = wg_any ? 1u : 0u;
     if (MODE == SB_COLLIDE_GRID) SB_STAMP(job.step, 6);
+#ifdef SB_STAMPS
+    if (MODE == SB_COLLIDE_GRID && blockIdx.x == gridDim.x / 2u && threadIdx.x == 0u && job.step.stamps[9] > job.step.stamps[8] && job.step.stamps[8] > job.step.stamps[5]) {
+        for (int k = 0; k < 12; k++) job.step.stamps[16 + k] = job.step.stamps[k]; // the last launch that made its lists together
+        job.step.stamps[8] = job.step.stamps[9] = 0u;
+    }
+#endif
 }
 
 // The two entry points.  With the collision walk compiled in, the body wants 71 VGPRs: 7 waves per SIMD, i.e.
@@ -846,6 +881,9 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
         job.step = sbk_grid_step(e, sched);
         job.build = gb;
         job.pslot = e->d_pslot;
+        job.islot = e->d_islot;
+        job.coop_off = e->lds_coop_off;
+        job.coop_bytes = e->d_islot ? e->lds_coop : 0u;
     }
     if (e->path == SB_PATH_ATOMIC) {
         if (e->nbeam)
@@ -860,7 +898,8 @@ void sbk_launch_substep(sb_engine *e, bool write_aux)
 #undef SB_LAUNCH_P
         }
     } else if (e->ntiles) {
-#define SB_LAUNCH_T(K, T, A) K<T, A><<<e->ntiles, SB_TILE_BLOCK, e->lds_bytes, e->stream>>>(                            \
+    const size_t lds_launch = (mode == SB_COLLIDE_GRID && job.coop_bytes) ? (size_t)e->lds_coop_off + e->lds_coop : e->lds_bytes;
+#define SB_LAUNCH_T(K, T, A) K<T, A><<<e->ntiles, SB_TILE_BLOCK, lds_launch, e->stream>>>(                            \
         r, w, e->beams, e->d_tile_p0, e->d_tile_b0, e->d_tile_h0, e->d_halo_idx, e->ntiles, e->tile_cap_all,       \
         e->tile_cap_own, e->lbits, e->d_mat, e->nmat, e->consts, e->prm, e->d_broken, e->d_pidx, e->grid,          \
         job, e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1])

@@ -946,6 +946,9 @@ struct SbGridJob {
     SbGridStep step;
     SbGridBuild build;     // lagged schedule: the arrays a push writes
     const uint32_t *pslot; // ... and every particle's slot (its record carries it)
+    // cooperative list build (sb_lists_cooperative): internal index per slot, and the workgroup's LDS area for it
+    const uint32_t *islot;
+    uint32_t coop_off, coop_bytes; // byte offset into the dynamic LDS, size (0: none -- every particle walks the hash for itself)
 };
 
 // The hash is a linked list per cell (r02; round 1 counted, scanned and scattered into cell-sorted records: three
@@ -1108,6 +1111,205 @@ SB_DEV uint32_t sb_neighbour_list_build(const SbGrid &g, const SbGridGeom &m, ui
     }
     g.nl_count[i] = n;
     return n;
+}
+
+// ---- the neighbour lists of a whole tile, made by its workgroup TOGETHER through LDS (r04; `north_star`: "LDS-staged spatial-hash
+// cell buckets").  sb_neighbour_list_build has every particle load the nine list heads around its cell and chase nine chains of
+// 16-byte records through global memory: three dependent trips per particle, each record fetched by every particle near it
+// (r02 counters: the walk is bound by those per-lane loads).  A tile is spatially compact, so the cells its particles need are the
+// bounding rectangle of their own cells plus a rim of one: the workgroup loads every head of that rectangle once (coalesced along
+// rows), walks every chain once and leaves each record in LDS as 8 bytes -- its position quantised to 16 bits per axis RELATIVE TO
+// THE RECTANGLE (a list only has to be a superset of "everybody within 2r + 2 skin at build time": the reach is widened by three
+// quantisation steps) and its slot -- a contiguous block of records per cell.  Every particle then selects its neighbours out of LDS,
+// in ascending slot order as before (the SB_NL_SEL smallest slots above the last one taken, per sweep), and turns slots into
+// internal indices through `islot` only for the entries it stores.  Returns false (uniform, nothing written) when the rectangle
+// or its records do not fit the area -- a tile that has scattered (free particles after a long flight): the caller falls back on
+// sb_neighbour_list_build.  Same lists as that function up to extra entries at the rim of the reach; the contacts taken from them
+// are decided on current positions at walk time, so the physics is the same bit for bit.
+struct SbCoopMeta {
+    int minx, maxx, miny, maxy;
+    uint32_t nrec, fail, pad_[2];
+};
+#define SB_COOP_ANYWHERE 0xFFFFFFFFu // quantised position of a record that cannot be placed (clamped into an edge cell from outside the frame, NaN): always a candidate
+#define SB_COOP_CPT 3                // cells a thread loads side by side (512 threads x 3 cover the ~1400 cells an area holds in one round)
+SB_DEV uint32_t sb_coop_quantise(float x, float y, float ox, float oy, float to_q)
+{
+    const float ux = (x - ox) * to_q, uy = (y - oy) * to_q;
+    return (ux >= 0.0f && ux < 65535.0f && uy >= 0.0f && uy < 65535.0f) ? ((uint32_t)ux | ((uint32_t)uy << 16)) : SB_COOP_ANYWHERE; // (false for NaN)
+}
+SB_DEV bool sb_lists_cooperative(const SbGrid &g, const SbGridGeom &m, uint32_t p0, uint32_t n_own, const uint32_t *__restrict__ pslot,
+                                 const uint32_t *__restrict__ islot, unsigned char *area, uint32_t area_bytes
+#ifdef SB_STAMPS
+                                 , const SbGridStep &dbg, uint64_t sb_t_start
+#endif
+)
+{
+    SbCoopMeta *meta = (SbCoopMeta *)area;
+    const uint32_t cap = (area_bytes - (uint32_t)sizeof(SbCoopMeta)) / 12u; // per record 8 bytes, per cell 4 (first record | count << 16)
+    uint2 *s_rec = (uint2 *)(area + sizeof(SbCoopMeta));
+    uint32_t *s_cell = (uint32_t *)(s_rec + cap);
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63u;
+    if (tid == 0u) {
+        meta->minx = meta->miny = 0x7fffffff;
+        meta->maxx = meta->maxy = -1;
+        meta->nrec = meta->fail = 0u;
+    }
+    __syncthreads();
+    { // the rectangle of the tile's own cells (reduced per wave first: 512 lanes on four LDS words would queue up behind each other)
+        int lox = 0x7fffffff, hix = -1, loy = 0x7fffffff, hiy = -1;
+        for (uint32_t i = tid; i < n_own; i += nthreads) {
+            const uint32_t c = g.cell_of[p0 + i];
+            const int cx = (int)(c % m.nx), cy = (int)(c / m.nx);
+            lox = min(lox, cx);
+            hix = max(hix, cx);
+            loy = min(loy, cy);
+            hiy = max(hiy, cy);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lox = min(lox, __shfl_xor(lox, off, 64));
+            hix = max(hix, __shfl_xor(hix, off, 64));
+            loy = min(loy, __shfl_xor(loy, off, 64));
+            hiy = max(hiy, __shfl_xor(hiy, off, 64));
+        }
+        if (lane == 0u) {
+            atomicMin(&meta->minx, lox);
+            atomicMax(&meta->maxx, hix);
+            atomicMin(&meta->miny, loy);
+            atomicMax(&meta->maxy, hiy);
+        }
+    }
+    __syncthreads();
+    SB_STAMP(dbg, 10);
+    const int x_lo = meta->minx - 1, y_lo = meta->miny - 1; // (with the rim)
+    const uint32_t w = (uint32_t)(meta->maxx - meta->minx + 3), h = (uint32_t)(meta->maxy - meta->miny + 3);
+    if (n_own == 0u || cap < 64u || cap > 0xFFF0u || (unsigned long long)w * h > cap) return false; // (uniform: every thread reads the same words)
+    const uint32_t ncell = w * h;
+    // the rectangle in world units and the quantisation step
+    const float ox = m.x0 + (float)x_lo * m.cell, oy = m.y0 + (float)y_lo * m.cell;
+    const float extent = fmaxf((float)w, (float)h) * m.cell, to_q = 65536.0f / extent, res = extent * (1.0f / 65536.0f);
+    // ---- every chain of the rectangle once: SB_COOP_CPT cells per thread side by side (heads together, first records together;
+    // a chain longer than one record -- rare: cells are about one particle wide -- is walked to its end for the count and again
+    // to fill), a contiguous block of records per cell, allocated per wave (one LDS add per wave, not per record)
+    for (uint32_t base = 0; base < ncell; base += nthreads * SB_COOP_CPT) {
+        uint32_t first[SB_COOP_CPT], count[SB_COOP_CPT];
+        float4 r0[SB_COOP_CPT];
+        unsigned long long hd[SB_COOP_CPT];
+#pragma unroll
+        for (int u = 0; u < SB_COOP_CPT; u++) {
+            const uint32_t t = base + tid + (uint32_t)u * nthreads;
+            const int gx = x_lo + (int)(t % w), gy = y_lo + (int)(t / w);
+            const bool in = t < ncell && gx >= 0 && gy >= 0 && gx < (int)m.nx && gy < (int)m.ny;
+            hd[u] = g.head[in ? (uint32_t)gy * m.nx + (uint32_t)gx : 0u];
+            if (!in) hd[u] = 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < SB_COOP_CPT; u++) {
+            first[u] = (uint32_t)(hd[u] >> 32) == m.gen ? (uint32_t)hd[u] : SB_CHAIN_END; // (gen >= 1: 0 is never current)
+            r0[u] = g.rec[first[u] != SB_CHAIN_END ? first[u] : 0u];
+        }
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int u = 0; u < SB_COOP_CPT; u++) {
+            count[u] = first[u] != SB_CHAIN_END ? 1u : 0u;
+            if (count[u]) {
+                uint32_t cur = __float_as_uint(r0[u].w);
+                while (cur != SB_CHAIN_END && count[u] < 0xFFFFu) { // (rare)
+                    count[u]++;
+                    cur = __float_as_uint(g.rec[cur].w);
+                }
+            }
+            mine += count[u];
+        }
+        // this wave's block of records: an inclusive scan of the lanes' totals, one add by the last lane
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += v;
+        }
+        uint32_t wave_base = 0u;
+        if (lane == 63u) wave_base = atomicAdd(&meta->nrec, incl);
+        wave_base = __shfl(wave_base, 63, 64);
+        uint32_t at = wave_base + incl - mine;
+        if (at + mine > cap) {
+            meta->fail = 1u;
+            mine = 0u; // (nothing is written; the caller falls back)
+        }
+#pragma unroll
+        for (int u = 0; u < SB_COOP_CPT; u++) {
+            const uint32_t t = base + tid + (uint32_t)u * nthreads;
+            if (t < ncell) s_cell[t] = mine ? (at | (count[u] << 16)) : 0u;
+            if (mine && count[u]) {
+                s_rec[at] = make_uint2(sb_coop_quantise(r0[u].x, r0[u].y, ox, oy, to_q), __float_as_uint(r0[u].z));
+                uint32_t cur = __float_as_uint(r0[u].w);
+                for (uint32_t j = 1; j < count[u]; j++) { // (rare)
+                    const float4 r = g.rec[cur];
+                    s_rec[at + j] = make_uint2(sb_coop_quantise(r.x, r.y, ox, oy, to_q), __float_as_uint(r.z));
+                    cur = __float_as_uint(r.w);
+                }
+                at += count[u];
+            }
+        }
+    }
+    __syncthreads();
+    SB_STAMP(dbg, 11);
+    if (meta->fail != 0u) return false;
+    // ---- every own particle: its neighbours out of LDS, in ascending slot order
+    const float reach = sb_sqrt(m.reach2) + 3.0f * res, reach_q2 = reach * reach * to_q * to_q; // (m.reach2 already carries a rounding margin)
+    for (uint32_t i = tid; i < n_own; i += nthreads) {
+        const uint32_t gi = p0 + i, c = g.cell_of[gi], own_slot = pslot[gi];
+        const float4 own = g.rec[gi];
+        const float px = (own.x - ox) * to_q, py = (own.y - oy) * to_q; // (in quantisation steps, like the records; NaN: every test below fails -> kept)
+        const uint32_t lx = (uint32_t)((int)(c % m.nx) - x_lo), ly = (uint32_t)((int)(c / m.nx) - y_lo);
+        uint32_t sc[9]; // the nine cells' blocks, requested together
+#pragma unroll
+        for (int nb = 0; nb < 9; nb++) sc[nb] = s_cell[(ly + (uint32_t)(nb / 3) - 1u) * w + (lx + (uint32_t)(nb % 3) - 1u)];
+        uint32_t n = 0u, last = 0u;
+        bool have_last = false;
+        for (;;) {
+            uint32_t bs[SB_NL_SEL];
+#pragma unroll
+            for (int q = 0; q < SB_NL_SEL; q++) bs[q] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int nb = 0; nb < 9; nb++) {
+                const uint32_t k0 = sc[nb] & 0xFFFFu, kn = sc[nb] >> 16;
+                for (uint32_t j = 0; j < kn; j++) {
+                    const uint2 r = s_rec[k0 + j];
+                    uint32_t slot = r.y;
+                    const float dx = ((float)(r.x & 0xFFFFu) + 0.5f) - px, dy = ((float)(r.x >> 16) + 0.5f) - py;
+                    const bool far = r.x != SB_COOP_ANYWHERE && dx * dx + dy * dy > reach_q2; // (NaN compares false: kept)
+                    if ((slot == own_slot) | (have_last & (slot <= last)) | (slot >= bs[SB_NL_SEL - 1]) | far) continue;
+#pragma unroll
+                    for (int q = 0; q < SB_NL_SEL; q++) { // carry the larger one down the registers
+                        const bool lt = slot < bs[q];
+                        const uint32_t ts = lt ? bs[q] : slot;
+                        bs[q] = lt ? slot : bs[q];
+                        slot = ts;
+                    }
+                }
+            }
+            bool full = true;
+#pragma unroll
+            for (int q = 0; q < SB_NL_SEL; q++) {
+                if (bs[q] == 0xFFFFFFFFu) {
+                    full = false;
+                } else if (n != SB_NL_OVERFLOW) {
+                    if (n == SB_NL_CAP) {
+                        n = SB_NL_OVERFLOW;
+                    } else {
+                        g.nl[n * g.nl_stride + gi] = islot[bs[q]];
+                        n++;
+                        last = bs[q];
+                        have_last = true;
+                    }
+                }
+            }
+            if (!full || n == SB_NL_OVERFLOW) break;
+        }
+        g.nl_count[gi] = n;
+    }
+    return true;
 }
 
 // The collision loop of compute.wgsl:144-170 over particle i's neighbour list (`count` = nl_count[i], fetched

@@ -148,6 +148,51 @@ print("CLASSIC_OK", eng.info("grid_builds"))
 """
 
 
+NO_COOP = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "oracle"))
+import __graft_entry__ as ge
+import oracle
+sb = ge.load_package()
+pile, bounds = sb.scenes.blob_pile_buffers(8, 4, gap=19.6)
+eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=pile.max_particles, max_beams=pile.max_beams, collision_mode=2, tile_particles=128)
+eng.write_buffers(pile)
+eng.step(200)
+got = eng.load_buffers(pile.copy())
+ref = oracle.OracleEngine(bounds, 10.0, 64, 2, 2, threads=8)
+ref.write_buffers(pile)
+ref.step(200)
+exp = ref.load_buffers(pile.copy())
+assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")) and got.beams.tobytes() == exp.beams.tobytes()
+assert eng.info("grid_builds") >= 3
+print("COOP_RUN_OK")
+"""
+
+
+def test_lists_made_per_particle_when_the_cooperative_build_is_off(sb, oracle):
+    """The neighbour lists of a tile are made by its workgroup together through LDS (sb_lists_cooperative); a tile that has
+    scattered falls back on every particle walking the hash for itself.  SB_GRID_COOP=0 takes that path everywhere: same bits
+    (a pile of touching blobs, 200 substeps, both against the oracle's grid mode)."""
+    pile, bounds = sb.scenes.blob_pile_buffers(8, 4, gap=19.6)
+    ref = oracle.OracleEngine(bounds, 10.0, 64, 2, GRID, threads=8)
+    ref.write_buffers(pile)
+    ref.step(200)
+    exp = ref.load_buffers(pile.copy())
+    eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=pile.max_particles, max_beams=pile.max_beams, collision_mode=GRID, tile_particles=128)
+    eng.write_buffers(pile)
+    eng.step(200)
+    got = eng.load_buffers(pile.copy())
+    builds = eng.info("grid_builds")
+    eng.destroy()
+    assert_same(got, exp, "pile, lists made together")
+    assert builds >= 3
+    env = dict(os.environ, SB_GRID_COOP="0", SB_HYBRID="0", GRAFT_REPO_ROOT=ROOT)   # (read once per process: own process)
+    p = subprocess.run([sys.executable, "-c", NO_COOP], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "COOP_RUN_OK" in p.stdout, p.stdout + p.stderr
+
+
 def test_classic_schedule_forced(sb):
     """SB_GRID_MODE=classic (read once per process: own process): the fallback schedule on its own -- a helper launch in front of
     every substep, which takes the substep's decision itself and builds when that says so -- on the reference's default scene

@@ -37,4 +37,7 @@ for name in which:
     if os.environ.get("STAMPS"):   # a -DSB_STAMPS build: one mid-grid workgroup of the LAST launch, us since its start
         print("       stamps (us): begin-issued %.2f staged %.2f barrier1 %.2f decided %.2f barrier2 %.2f beams-done %.2f end %.2f"
               % tuple(eng.info("grid_stamp_%d" % k) / 100.0 for k in range(7)), flush=True)
+        f = [eng.info("grid_stamp_%d" % (16 + k)) / 100.0 for k in range(12)]
+        print("       last list-making launch (us): barrier1 %.2f decided %.2f beams-done %.2f coop-start %.2f rectangle %.2f records-in-LDS %.2f coop-done %.2f end %.2f"
+              % (f[2], f[4], f[5], f[8], f[10], f[11], f[9], f[6]), flush=True)
     eng.destroy()
