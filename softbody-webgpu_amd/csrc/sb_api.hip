@@ -1923,6 +1923,11 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "substep_hbm_bytes") *value = substep_bytes_model(e);
     else if (k == "substeps_per_launch") *value = e->bk.K ? e->bk.k_long : 1; // of a long call (sbk_split_call)
     else if (k == "plan_depth") *value = e->bk.K ? e->bk.K : 1;
+    else if (k.rfind("block_redundancy_x1000_", 0) == 0) { // beam evaluations per beam and substep of a launch of <k> substeps, in thousandths (ring redundancy of the blocked plan)
+        const int d = atoi(key + 23);
+        const SbBlockedDev &bk = e->bk.K ? e->bk : e->hy;
+        *value = (bk.K && d >= 1 && d <= (int)bk.K && bk.nbeams) ? (uint64_t)(1000.0 * (double)bk.entries_at[d] / (double)bk.nbeams + 0.5) : 0;
+    }
     else if (k == "region_particles") *value = e->bk.K ? e->bk.cap : e->tile_cap_all;
     else if (k == "tiles") *value = e->ntiles;
     else if (k == "beam_copies") *value = e->bk.K ? e->bk.entries_at[e->bk.k_long] : e->nbeam;
