@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CTL_WORDS = ["fresh", "need_build", "pushing", "abort", "cur", "executed", "builds", "since", "accum", "cx", "cy", "Cx", "Cy", "skin_min",
-             "skin_max", "wide_next", "settled", "transient", "short_lived", "pad0", "pad1", "pad2", "skin"]
+             "skin_max", "wide_next", "settled", "transient", "short_lived", "pad0", "pad1", "pad2", "skin"]   # (sb_physics.h SbGridCtl)
 CTL_FLOATS = {"accum", "cx", "cy", "Cx", "Cy", "skin_min", "skin_max", "skin"}
 
 
@@ -89,6 +89,34 @@ def test_the_bound_bounds(sb, oracle, monkeypatch):
         prev = now
     eng.destroy()
     assert checked >= 5, checked
+
+
+def test_the_bound_covers_the_last_substep_when_the_hybrid_looks(sb, oracle):
+    """the hybrid's look read the bound of the state BEFORE the last single substep and started its tracked
+    run one substep short.  The look now takes the next substep's decision ahead of time (k_grid_settle) and a tracked run hands
+    its bound back as a settled block: after every call that went through a look, `accum` and (Cx, Cy) must cover the CURRENT
+    positions (the hash of the forced first build holds the uploaded ones) -- and the run is the oracle's, bit for bit."""
+    buf = sb.scenes.lattice_buffers(48, 40, d=30.0, origin=(200.0, 600.0), jitter=0.15, layout=2, velocity=(1.5, -2.0))
+    P = buf.particle_count
+    eng, ref = engines(sb, oracle, buf, 4000.0, ref_mode=GRID, tile_particles=256)
+    p0 = buf.particles[:P, :2].astype("f8")
+    checked = 0
+    for call in range(12):
+        eng.step(5)
+        ref.step(5)
+        c = ctl(eng)
+        if c["builds"] != 1:
+            break   # (a second hash: its origin is no longer the upload)
+        if c["settled"]:   # the block a tracked run (or a look) left: it describes the state the NEXT substep reads, i.e. now
+            now = eng.load_buffers(buf.copy()).particles[:P, :2].astype("f8")
+            rel = np.abs(now - p0 - np.array([c["Cx"], c["Cy"]])).max()
+            assert rel <= c["accum"] * (1 + 1e-5) + 1e-6, (call, rel, c)
+            checked += 1
+    blocked = eng.info("hybrid_substeps")
+    got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+    eng.destroy()
+    assert_same(got, exp, "quiet lattice in calls of five")
+    assert checked >= 3 and blocked >= 10, (checked, blocked)
 
 
 def test_a_sudden_kick_aborts_and_recovers(sb, oracle, monkeypatch):

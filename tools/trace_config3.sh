@@ -1,26 +1,25 @@
-mkdir -p gpurun_out/r02d
-export TMPDIR=/tmp
+#!/bin/bash
+# Per-launch durations of config 3's substep kernel from a rocprofv3 kernel trace (GPU box): since r04 the substep kernel is the
+# only launch of a substep, and its launches come in three kinds -- ordinary, push (the workgroups push the next hash as they go)
+# and list-making -- which the durations tell apart.  Usage: tools/trace_config3.sh [pile|soup|floor|quiet]   (env: SB_GRID_COOP=0,
+# SB_GRID_MODE=classic for A/B runs); prints mean / median / percentiles and the split at 45 us.
+SCENE=${1:-pile}
 ROOT=$PWD
+OUT=$ROOT/gpurun_out/trace_config3
+mkdir -p $OUT
+export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/r02d/trace_cfg3 -- python3 $ROOT/bench.py --config3 --steps 400 --warmup 16 --no-cpu-baseline > $ROOT/gpurun_out/r02d/trace_cfg3.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/r02d/trace_soup -- python3 $ROOT/bench.py --soup --steps 400 --warmup 16 --no-cpu-baseline > $ROOT/gpurun_out/r02d/trace_soup.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $ROOT/tools/grid_schedule_probe.py $SCENE > $OUT/probe.log 2>&1
 cd $ROOT
-for d in trace_cfg3 trace_soup; do echo == $d; tail -1 gpurun_out/r02d/$d.log | cut -c1-200; python3 - gpurun_out/r02d/$d <<'PY'
+grep us/substep $OUT/probe.log
+python3 - $OUT/tr <<'PY'
 import csv, glob, sys
-for f in glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"):
-    for r in csv.DictReader(open(f)):
-        print("%-70s calls %6s avg us %9.2f total ms %8.2f  %5s%%" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
-# rebuild substeps against the others: the maintain launches split at 10 us, and the particle launch that follows each
-for f in glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"):
-    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    acc = {}
-    for a, b in zip(rows, rows[1:]):
-        if "k_grid_maintain" in a["Kernel_Name"] and "k_substep" in b["Kernel_Name"]:
-            key = "rebuild" if dur(a) > 10.0 else "keep"
-            acc.setdefault(key, []).append((dur(a), dur(b), (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3))
-    for key, v in acc.items():
-        n = len(v)
-        print("  %-8s substeps %5d: maintain %.2f us, gap %.2f us, particle kernel %.2f us" % (key, n, sum(x[0] for x in v) / n, sum(x[2] for x in v) / n, sum(x[1] for x in v) / n))
+f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+rows = sorted((r for r in csv.DictReader(open(f)) if "k_substep_tiled_grid" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows][-960:]   # the timed region of the probe
+s, n = sorted(d), len(d)
+print("launches %d: mean %.2f median %.2f p80 %.2f p90 %.2f p95 %.2f max %.2f us" % (n, sum(d) / n, s[n // 2], s[int(n * .8)], s[int(n * .9)], s[int(n * .95)], s[-1]))
+slow, fast = [x for x in d if x > 45], [x for x in d if x <= 45]
+print("   <= 45 us: %d launches, mean %.2f;  > 45 us (list-making): %d launches, mean %.2f" % (len(fast), sum(fast) / max(len(fast), 1), len(slow), sum(slow) / max(len(slow), 1)))
 PY
-done
+rm -rf $OUT/tr
