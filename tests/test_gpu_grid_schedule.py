@@ -43,11 +43,11 @@ def engines(sb, oracle, buf, bounds, ref_mode=ALLPAIRS, **kw):
     return eng, ref
 
 
-def test_lagged_schedule_needs_no_helper_launches(sb, oracle, monkeypatch):
-    """A gas of 1600 free particles that meet all the time, 320 substeps in calls of 1 to 64: after the forced build of the
+def test_lagged_schedule_needs_no_helper_launches(sb, oracle):
+    """(No beams in these gases: the engine never keeps a blocked plan beside them -- the switch SB_HYBRID is read once per process and
+    is not touched here.)  A gas of 1600 free particles that meet all the time, 320 substeps in calls of 1 to 64: after the forced build of the
     first substep every hash is pushed by the substep kernels themselves (several of them), no launch is aborted, and the result
     is the all-pairs scan's."""
-    monkeypatch.setenv("SB_HYBRID", "0")
     buf = gas(sb)
     eng, ref = engines(sb, oracle, buf, 1900.0, tile_particles=128)
     assert eng.info("grid_schedule") == 0
@@ -64,11 +64,10 @@ def test_lagged_schedule_needs_no_helper_launches(sb, oracle, monkeypatch):
     assert info["grid_helper_launches"] == 1 and info["grid_classic_substeps"] == 0 and info["kernels_per_substep"] == 1, info
 
 
-def test_the_bound_bounds(sb, oracle, monkeypatch):
+def test_the_bound_bounds(sb, oracle):
     """The bookkeeping's own invariant, read off the device: after m substeps the control block says `accum` (D) and (Cx, Cy)
     (the drift C) for the READ state of substep m + 1 -- every particle's displacement since the hash in use was built, minus C,
     must be within D.  The hash of a forced build holds the uploaded positions (age = substeps since the upload)."""
-    monkeypatch.setenv("SB_HYBRID", "0")
     buf = sb.scenes.lattice_buffers(48, 40, d=30.0, origin=(200.0, 600.0), jitter=0.15, layout=2, velocity=(1.5, -2.0))
     P = buf.particle_count
     eng, ref = engines(sb, oracle, buf, 4000.0, ref_mode=GRID, tile_particles=256)
@@ -119,14 +118,13 @@ def test_the_bound_covers_the_last_substep_when_the_hybrid_looks(sb, oracle):
     assert checked >= 3 and blocked >= 10, (checked, blocked)
 
 
-def test_a_sudden_kick_aborts_and_recovers(sb, oracle, monkeypatch):
+def test_a_sudden_kick_aborts_and_recovers(sb, oracle):
     """The lagged schedule predicts the next substep's displacement from the last one's.  A user force that appears between two
     calls (engineWorker.ts:636-642: input is written per frame) and lasts two substeps throws every particle forward three to
     six units per substep where a fifth of one was predicted (the common drift the bound is measured against lags one substep
     behind): some launch finds its lists not known to be valid, raises `abort`, the launches behind it return at once, and
     the host redoes them behind a fresh hash in the classic schedule -- in which the gas, now fast, stays.  Same bits as the
     all-pairs scan; and the abort really happened."""
-    monkeypatch.setenv("SB_HYBRID", "0")
     buf = gas(sb, n_side=36, speed=6.0, seed=9)
     eng, ref = engines(sb, oracle, buf, 1800.0, tile_particles=128)
     eng.step(40)
