@@ -90,30 +90,40 @@ static void pool_trim(sb_engine *e)
         if (_s != SB_OK) return _s;        \
     } while (0)
 
-// Waiting for the engine's stream where the wait is SHORT (the end of a call's launches, the looks of the spatial hash): poll
-// for a third of a millisecond before falling back on the blocking wait.  hipStreamSynchronize parks the thread, and being woken
-// costs 20-50 us on this stack -- 10 % of the driver's 20-substep protocol at 1 M particles (0.31 ms), and as much as the
-// kernels of a small scene's frame.
-static hipError_t sb_stream_wait(hipStream_t stream)
+// Waiting for the engine's stream where the wait is SHORT (the end of a call's launches, the looks of the spatial hash, a run of
+// blocked launches under the hash): poll for `spin_us` before falling back on the blocking wait.  hipStreamSynchronize parks the
+// thread, and being woken costs 20-50 us on a good day on this stack and several hundred on a bad one (r04: the lattice on the
+// floor, 32 looks and runs per 1000 substeps, read 28.5 us per substep on one box and 39-44 on another with every wait behind a
+// run parked) -- 10 % of the driver's 20-substep protocol at 1 M particles, and as much as the kernels of a small scene's frame.
+// Callers pass what the work in flight should take (default: a third of a millisecond); SB_WAIT_SPIN_US overrides every site
+// (0: always park).
+static int64_t sb_spin_override()
 {
+    static const int64_t v = [] { const char *s = getenv("SB_WAIT_SPIN_US"); return s ? (int64_t)atoll(s) : (int64_t)-1; }();
+    return v;
+}
+static hipError_t sb_stream_wait(hipStream_t stream, int64_t spin_us = 330)
+{
+    if (sb_spin_override() >= 0) spin_us = sb_spin_override();
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery(stream);
         if (q != hipErrorNotReady) return q;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(330)) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
     return hipStreamSynchronize(stream);
 }
-static hipError_t sb_event_wait(hipEvent_t ev)
+static hipError_t sb_event_wait(hipEvent_t ev, int64_t spin_us = 330)
 {
+    if (sb_spin_override() >= 0) spin_us = sb_spin_override();
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipEventQuery(ev);
         if (q != hipErrorNotReady) return q;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(330)) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
@@ -1428,7 +1438,7 @@ static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
             continue;
         }
         SB_HIP(e, hipMemcpyAsync(pin, e->d_grid_ctl, 2 * sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
-        SB_HIP(e, sb_stream_wait(e->stream));
+        SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)chunk * (int64_t)(10u + e->P / 25000u), 8000)));
         if (!(pin[0].abort | pin[1].abort)) {
             m -= chunk;
             if (pin[e->grid_par].short_lived != 0u) { // hashes last four substeps or less: the classic schedule serves such a scene better
@@ -1611,7 +1621,8 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         const uint64_t done0 = e->substeps_done;
         sbk_hybrid_launch(e, ks, count, aux_last);
         SB_HIP(e, hipMemcpyAsync(pin, h.d_q, sizeof q, hipMemcpyDeviceToHost, e->stream));
-        SB_HIP(e, sb_stream_wait(e->stream));
+        // (the run is a few hundred microseconds to a few milliseconds of kernels, known in advance: poll for twice that)
+        SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)planned * (int64_t)(20u + e->P / 25000u), 8000)));
         q = *pin;
         const uint32_t done = std::min(q.done, count);
         // the host's idea of the buffers follows what the device really did
