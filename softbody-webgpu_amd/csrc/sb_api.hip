@@ -1161,7 +1161,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->lds_coop_off = e->lds_coop = 0;
         if (e->opt.collision_mode == SB_COLLIDE_GRID) {
             static const bool coop_off = [] { const char *v = getenv("SB_GRID_COOP"); return v && atoi(v) == 0; }();
-            const size_t quarter = 160 * 1024 / 4, fixed = 1024 /* the kernel's static LDS */ + 512 /* allocation granule */;
+            const size_t quarter = 160 * 1024 / (SB_GRID_WAVES / 2), fixed = 1024 /* the kernel's static LDS */ + 512 /* allocation granule */;
             const size_t off = (e->lds_bytes + 15) & ~(size_t)15;
             if (!coop_off && off + fixed + 8 * 1024 <= quarter) {
                 e->lds_coop_off = (uint32_t)off;

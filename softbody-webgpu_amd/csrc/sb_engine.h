@@ -26,6 +26,11 @@ struct SbParticleArrays {
     float2 *pos, *vel, *acc;
 };
 
+// waves per SIMD the hash-on single-substep kernel is compiled for (k_substep_tiled_grid: 8 = a cap of 64 VGPRs and four 8-wave
+// workgroups per CU, which is also the share of the CU's LDS a workgroup may use; 6 = 80 VGPRs, three workgroups)
+#ifndef SB_GRID_WAVES
+#define SB_GRID_WAVES 8
+#endif
 #define SB_BK_LBITS 12u  // bits per region-local endpoint index of the blocked kernel (regions of up to 4094 particles)
 #ifndef SB_BK_T
 #define SB_BK_T 512u     // threads per tile workgroup of k_substep_blocked

@@ -18,7 +18,9 @@
 #define SB_ABLATE 0
 #endif
 #define SB_TILE_BLOCK 512 // threads per tile workgroup: 8 waves (measured best: 256 x 4 20.6 us, 512 x 2 19.8 us, 1024 x 1 20.3 us)
+#ifndef SB_UNROLL
 #define SB_UNROLL 2     // owned particles / beam copies each thread has in flight at a time
+#endif
 #define SB_MAT_ROW 6u // length, spring, damp, yield, limit, 1/length
 
 // ---------------------------------------------------------------- SB_PATH_ATOMIC
@@ -508,9 +510,6 @@ __global__ __launch_bounds__(SB_TILE_BLOCK) void k_substep_tiled(SB_TILED_PARAMS
     sb_substep_tiled<SB_COLLIDE_OFF, MAT, AUX>(SB_TILED_ARGS);
 }
 template <int MAT, bool AUX>
-#ifndef SB_GRID_WAVES
-#define SB_GRID_WAVES 8
-#endif
 __global__ __launch_bounds__(SB_TILE_BLOCK) __attribute__((amdgpu_waves_per_eu(SB_GRID_WAVES, 8))) void k_substep_tiled_grid(SB_TILED_PARAMS)
 {
     sb_substep_tiled<SB_COLLIDE_GRID, MAT, AUX>(SB_TILED_ARGS);

@@ -1,5 +1,5 @@
 """Config-3 scenes under the two hash schedules of SbGridCtl (sb_physics.h): time per substep, hashes built, aborts, helper
-launches.  Usage: [SB_GRID_MODE=classic|lagged] python tools/grid_schedule_probe.py [pile] [soup] [floor] [quiet]  (GPU box)"""
+launches.  Usage: [SB_GRID_MODE=classic|lagged] python tools/grid_schedule_probe.py [pile] [soup] [floor] [quiet]  (GPU box; TILE=n: sb_options.tile_particles)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
@@ -21,7 +21,7 @@ for name in which:
         bounds, settle = 32000.0, 0
     os.environ["SB_HYBRID"] = "0"
     eng = sb.Engine(bounds_size=bounds, particle_radius=10.0, subticks=64, layout=2, max_particles=buf.max_particles,
-                    max_beams=buf.max_beams, collision_mode=2)
+                    max_beams=buf.max_beams, collision_mode=2, tile_particles=int(os.environ.get("TILE", "0")))
     eng.write_buffers(buf)
     for _ in range(settle):
         eng.frame()
