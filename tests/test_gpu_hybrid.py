@@ -120,3 +120,32 @@ def test_forced_roll_backs_are_invisible():
     env = dict(os.environ, SB_HYBRID_FAIL_EVERY="3")
     p = subprocess.run([sys.executable, "-c", FORCED % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0 and "forced roll-backs ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+PARKED = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import __graft_entry__ as ge
+sb, orc = ge.load_package(), ge.load_oracle()
+buf = sb.scenes.lattice_buffers(96, 64, d=30.0, origin=(300.0, 700.0), jitter=1.0, layout=2, velocity=(0.3, -0.8))
+eng = sb.Engine(bounds_size=5000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=2)
+ref = orc.OracleEngine(5000.0, 10.0, 64, 2, orc.COLLIDE_GRID, threads=16)
+eng.write_buffers(buf); ref.write_buffers(buf)
+for n in (64, 37, 64, 120):
+    eng.step(n); ref.step(n)
+eng.frame(); ref.frame()
+got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+assert eng.info("hybrid_substeps") > 100
+assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")) and got.beams.tobytes() == exp.beams.tobytes()
+print("parked waits ok", eng.info("hybrid_substeps"))
+"""
+
+
+def test_waits_that_park_instead_of_polling():
+    """Every look and every run of the hybrid path ends in a wait of the host for the stream, which polls for as long as the work in
+    flight should take before it parks the thread (sb_api.hip sb_stream_wait).  SB_WAIT_SPIN_US=0 (read once per process: a process
+    of its own) parks always -- the other branch of every such wait: same bits."""
+    env = dict(os.environ, SB_WAIT_SPIN_US="0")
+    p = subprocess.run([sys.executable, "-c", PARKED % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0 and "parked waits ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
