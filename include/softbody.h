@@ -137,7 +137,11 @@ sb_status sb_destroy(sb_engine *e);
  * An upload with the topology of the scene already on the device (same counts and mapping, every beam between the same
  * two particles with the same rest length and material; no ghost zones configured) keeps the engine's plan and only moves
  * state -- about a tenth of the time of an upload that plans (sb_get_info "uploads_kept" counts them); the results are
- * those of a fresh engine either way. */
+ * those of a fresh engine either way.  So does an upload that only REMOVED beams from that scene (at most an eighth of them; the
+ * beams that are left in their old order under any valid mapping, which is what BufferMapper.writeState produces after
+ * removeBeam calls or after a run whose delete passes removed beams, engineMapping.ts:452-459,500-518): the removed beams die on
+ * the device like beams a delete pass removed, counts / records / mapping read back exactly as from a fresh engine
+ * ("uploads_edited" counts those).  An upload that ADDS a beam plans again. */
 sb_status sb_write_buffers(sb_engine *e, const void *metadata, size_t metadata_bytes,
                            const void *mapping, size_t mapping_bytes,
                            const void *particles, size_t particles_bytes,

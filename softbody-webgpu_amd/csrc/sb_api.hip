@@ -682,6 +682,10 @@ sb_status sb_destroy(sb_engine *e)
     return SB_OK;
 }
 
+// the caller's beam slots (those of the latest upload) -> the engine's own (sb_engine.h h_user_slot)
+static inline uint32_t sb_user_beams(const sb_engine *e) { return e->h_user_slot.empty() ? e->B : (uint32_t)e->h_user_slot.size(); }
+static inline uint32_t sb_user_slot(const sb_engine *e, size_t u) { return e->h_user_slot.empty() ? (uint32_t)u : e->h_user_slot[u]; }
+
 // An upload of the SAME topology (same counts, same mapping, every beam between the same two particles with the same rest
 // length and material) as the scene on the device -- the editor moved or nudged something, or a caller steps from a saved
 // state again: everything the plan is made of (bisection, rings, entry lists, material rows, endpoint words, the hash's
@@ -695,47 +699,102 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
     static const bool off = [] { const char *v = getenv("SB_KEEP_PLAN"); return v && atoi(v) == 0; }();
     const uint32_t maxP = e->opt.max_particles, maxB = e->opt.max_beams, bstride = beam_stride(e);
     const uint32_t P = rd_u32(md + 4), B = rd_u32(md + 24);
-    const size_t map_bytes = (size_t)(maxP + (size_t)maxB) * map_isz(e);
-    if (off || !e->loaded || P != e->P || B != e->B || e->h_beams.size() != B || e->h_pidx.size() != P || e->h_mapping.size() != map_bytes)
+    const size_t map_bytes = (size_t)(maxP + (size_t)maxB) * map_isz(e), isz = map_isz(e);
+    const uint32_t Bu = e->loaded ? sb_user_beams(e) : 0u; // beams of the upload before this one, in the caller's slots
+    if (off || !e->loaded || P != e->P || B > Bu || e->h_beams.size() != e->B || e->h_pidx.size() != P || e->h_mapping.size() != map_bytes)
         return SB_OK;
+    if (Bu - B > Bu / 8u) return SB_OK; // (an edit, not another scene)
     if (e->n_ghost_p || e->n_send_p || e->n_ghost_b || e->n_send_b || e->n_peers || e->mailbox) return SB_OK; // (ghost zones: configured per upload)
     SbStageTimer tm;
     std::atomic<bool> same{true};
-    sbt::parallel_ranges(map_bytes, (size_t)1 << 20, [&](size_t a, size_t b) {
+    // the particle slots must map as before; the beam slots may map differently when beams were removed (the caller's slots are
+    // renumbered then: engineMapping.ts:500-518 writes the beams that are left in order, slot i at data index i)
+    const size_t cmp_bytes = B == Bu ? map_bytes : (size_t)maxP * isz;
+    sbt::parallel_ranges(cmp_bytes, (size_t)1 << 20, [&](size_t a, size_t b) {
         if (memcmp(mp + a, e->h_mapping.data() + a, b - a) != 0) same.store(false, std::memory_order_relaxed);
     });
     if (!same.load()) return SB_OK;
-    // beam records: endpoints and static parameters must match what the plan was made for; the state fields are taken over as
-    // we go (if a later record differs, the full path replaces every record anyway)
-    const bool v1 = e->opt.layout == SB_LAYOUT_V1;
-    sbt::parallel_ranges(B, 1 << 15, [&](size_t s0, size_t s1) {
-        if (!same.load(std::memory_order_relaxed)) return;
-        for (size_t s = s0; s < s1; s++) {
-            const uint8_t *rec = bd + (size_t)map_get(e, mp, (size_t)maxP + s) * bstride; // (the mapping is the validated one)
-            uint32_t a, b;
-            float f[9];
-            if (v1) {
-                const uint32_t pair = rd_u32(rec);
-                a = pair & 0xffffu;
-                b = pair >> 16;
-                memcpy(f, rec + 4, sizeof f);
-            } else {
-                a = rd_u32(rec);
-                b = rd_u32(rec + 4);
-                memcpy(f, rec + 8, sizeof f);
-            }
-            SbHostBeam &h = e->h_beams[s];
-            if (a != h.da || b != h.db || memcmp(&f[0], &h.f[0], 4) != 0 || memcmp(&f[3], &h.f[3], 16) != 0) {
-                same.store(false, std::memory_order_relaxed);
-                return;
-            }
-            h.f[1] = f[1];
-            h.f[2] = f[2];
-            h.f[7] = f[7];
-            h.f[8] = f[8];
+    if (B != Bu && memcmp(mp + (size_t)maxP * isz, e->h_mapping.data() + (size_t)maxP * isz, (size_t)B * isz) != 0) {
+        // a different map for the beams that are left: it has to be a partial injection like any other (sb_write_buffers_impl)
+        std::vector<uint8_t> seen((size_t)maxB, 0);
+        for (uint32_t u = 0; u < B; u++) {
+            const uint32_t idx = map_get(e, mp, (size_t)maxP + u);
+            if (idx >= maxB || seen[idx]) return SB_OK; // (the full path says what is wrong with it)
+            seen[idx] = 1;
         }
-    });
-    if (!same.load()) return SB_OK;
+    }
+    const bool v1 = e->opt.layout == SB_LAYOUT_V1;
+    // one record of the new upload against one beam of the engine: endpoints and static parameters must match what the plan was
+    // made for; the state fields are taken over on a match (if the upload turns out not to fit, the full path replaces every
+    // record anyway)
+    auto take = [&](size_t u, uint32_t s) -> bool {
+        const uint8_t *rec = bd + (size_t)map_get(e, mp, (size_t)maxP + u) * bstride;
+        uint32_t a, b;
+        float f[9];
+        if (v1) {
+            const uint32_t pair = rd_u32(rec);
+            a = pair & 0xffffu;
+            b = pair >> 16;
+            memcpy(f, rec + 4, sizeof f);
+        } else {
+            a = rd_u32(rec);
+            b = rd_u32(rec + 4);
+            memcpy(f, rec + 8, sizeof f);
+        }
+        SbHostBeam &h = e->h_beams[s];
+        if (a != h.da || b != h.db || memcmp(&f[0], &h.f[0], 4) != 0 || memcmp(&f[3], &h.f[3], 16) != 0) return false;
+        h.f[1] = f[1];
+        h.f[2] = f[2];
+        h.f[7] = f[7];
+        h.f[8] = f[8];
+        return true;
+    };
+    std::vector<uint32_t> user_slot; // (stays empty when the caller's slots are the engine's)
+    if (B == Bu) {
+        sbt::parallel_ranges(B, 1 << 15, [&](size_t s0, size_t s1) {
+            if (!same.load(std::memory_order_relaxed)) return;
+            for (size_t s = s0; s < s1; s++)
+                if (!take(s, sb_user_slot(e, s))) {
+                    same.store(false, std::memory_order_relaxed);
+                    return;
+                }
+        });
+        if (!same.load()) return SB_OK;
+        user_slot = e->h_user_slot;
+    } else {
+        // Beams were removed: the records that are left are a subsequence of the old ones (Map order, engineMapping.ts:510).  Any
+        // strictly increasing match of equal records will do.  In chunks: where each chunk starts in the old list is found one
+        // chunk after the other (the shift only grows, by the beams removed in between), the chunks are then matched side by side.
+        const size_t chunk = 1 << 15, nch = (B + chunk - 1) / chunk;
+        std::vector<uint32_t> start(nch + 1, Bu);
+        uint32_t op = 0;
+        for (size_t k = 0; k < nch && same.load(std::memory_order_relaxed); k++) {
+            const size_t u0 = k * chunk;
+            op = std::max<uint32_t>(op, (uint32_t)u0);
+            const uint8_t *rec = bd + (size_t)map_get(e, mp, (size_t)maxP + u0) * bstride;
+            const uint32_t a = v1 ? rd_u32(rec) & 0xffffu : rd_u32(rec), b = v1 ? rd_u32(rec) >> 16 : rd_u32(rec + 4);
+            while (op < Bu && (size_t)op - u0 <= (size_t)(Bu - B) && !(e->h_beams[sb_user_slot(e, op)].da == a && e->h_beams[sb_user_slot(e, op)].db == b)) op++;
+            if (op >= Bu || (size_t)op - u0 > (size_t)(Bu - B)) same.store(false, std::memory_order_relaxed);
+            start[k] = op;
+        }
+        if (!same.load()) return SB_OK;
+        user_slot.resize(B);
+        sbt::parallel_ranges(nch, 1, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1 && same.load(std::memory_order_relaxed); k++) {
+                uint32_t o = start[k];
+                const size_t u1 = std::min<size_t>((k + 1) * chunk, B);
+                for (size_t u = k * chunk; u < u1; u++) {
+                    while (o < start[k + 1] && !take(u, sb_user_slot(e, o))) o++;
+                    if (o >= start[k + 1]) { // (ran into the next chunk's beams, or off the end)
+                        same.store(false, std::memory_order_relaxed);
+                        return;
+                    }
+                    user_slot[u] = sb_user_slot(e, o++);
+                }
+            }
+        });
+        if (!same.load()) return SB_OK;
+    }
     tm.mark("same topology: mapping + beam records");
     std::vector<float2> hp(P), hv(P), ha(P);
     {
@@ -772,6 +831,7 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
     }
     // ---- from here on the scene on the device is rewritten
     e->h_metadata.assign(md, md + SB_METADATA_BYTES);
+    if (B != Bu) e->h_mapping.assign(mp, mp + map_bytes);
     e->cur = 0;
     e->substeps_done = 0;
     if (e->dev_err) *e->dev_err = 0;
@@ -824,8 +884,34 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
     }
     if (e->d_forces) SB_HIP(e, hipMemsetAsync(e->d_forces, 0, std::max<size_t>(P, 1) * sizeof(int2), e->stream));
     SB_HIP(e, hipMemsetAsync(e->d_broken, 0, std::max<size_t>((nc + 31) / 32, 1) * 4, e->stream));
-    SB_HIP(e, hipMemsetAsync(e->d_dead_gen, 0, std::max<size_t>(B, 1) * 4, e->stream));
+    SB_HIP(e, hipMemsetAsync(e->d_dead_gen, 0, std::max<size_t>(e->B, 1) * 4, e->stream));
     e->delete_gen = 0;
+    // The engine's beams that are not part of the scene any more (removed by this upload or by one before it) die like beams a
+    // delete pass removes -- every copy / entry of them, in a pass of its own that is the upload's: generation 1; the passes of
+    // the frames that follow count from 2, and none of the caller's slots ever carries 1.
+    if (!user_slot.empty()) {
+        std::vector<uint8_t> live(e->B, 0);
+        for (uint32_t s : user_slot) live[s] = 1;
+        const uint32_t *slot_of = e->bk.K ? e->bk.h_beam_slot.data() : e->h_slot_of_copy.data();
+        const size_t n_of = e->bk.K ? e->bk.h_beam_slot.size() : e->h_slot_of_copy.size();
+        if (n_of != nc) SB_FAIL(e, SB_ERR_STATE, "plan-keeping upload: %zu copies in the host map, %u on the device", n_of, nc);
+        std::vector<uint32_t> mask((nc + 31) / 32, 0u);
+        sbt::parallel_ranges(mask.size(), 1 << 12, [&](size_t w0, size_t w1) {
+            for (size_t w = w0; w < w1; w++) {
+                uint32_t bits = 0u;
+                for (uint32_t k = 0; k < 32u && w * 32 + k < nc; k++) {
+                    const uint32_t sl = slot_of[w * 32 + k];
+                    if (sl != 0xFFFFFFFFu && !live[sl]) bits |= 1u << k;
+                }
+                mask[w] = bits;
+            }
+        });
+        SB_TRY(stage_put_bytes(e, e->d_broken, mask.data(), mask.size() * 4));
+        if (e->bk.K) sbk_launch_delete_blocked(e);
+        else sbk_launch_delete(e);
+        e->uploads_edited += B != Bu ? 1u : 0u;
+    }
+    e->h_user_slot.swap(user_slot);
     if (e->opt.collision_mode == SB_COLLIDE_GRID && e->d_grid_ctl) { // the hash: no build yet, same frame
         for (int k = 0; k < 2; k++) SB_HIP(e, hipMemsetAsync(e->d_head[k], 0, e->grid_heads * 8, e->stream));
         SB_HIP(e, hipMemsetAsync(e->d_blk_max, 0, e->grid_slots * 4, e->stream));
@@ -888,6 +974,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
     e->h_mapping.assign(mp, mp + (size_t)(maxP + (size_t)maxB) * map_isz(e));
     e->P = P;
     e->B = B;
+    e->h_user_slot.clear();
     e->cur = 0;
     e->substeps_done = 0;
 
@@ -1814,17 +1901,19 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
     if (mapping) {
         // replay the per-frame stable in-place compactions of the beam slots, pass by pass
         // (compute.wgsl:221-233 intent); slots past the live count keep stale values
+        // (over the CALLER's slots, those of the latest upload: beams an upload removed are in none of them -- sb_engine.h h_user_slot)
         uint8_t *m = (uint8_t *)mapping;
         memcpy(m, e->h_mapping.data(), e->h_mapping.size());
         if (nd) {
+            const uint32_t Bu = sb_user_beams(e);
             std::vector<uint32_t> gens;
-            for (uint32_t g : dead)
-                if (g) gens.push_back(g);
+            for (uint32_t u = 0; u < Bu; u++)
+                if (dead[sb_user_slot(e, u)]) gens.push_back(dead[sb_user_slot(e, u)]);
             std::sort(gens.begin(), gens.end());
             gens.erase(std::unique(gens.begin(), gens.end()), gens.end());
-            std::vector<uint32_t> orig(B);
-            std::iota(orig.begin(), orig.end(), 0u);
-            uint32_t count = B;
+            std::vector<uint32_t> orig(Bu);
+            for (uint32_t u = 0; u < Bu; u++) orig[u] = sb_user_slot(e, u);
+            uint32_t count = Bu;
             for (uint32_t g : gens) {
                 uint32_t w = 0;
                 for (uint32_t s = 0; s < count; s++)
@@ -1865,11 +1954,12 @@ static sb_status sb_load_buffers_impl(sb_engine *e, void *metadata, size_t metad
         tm.mark("readback: beam state to host");
         uint8_t *out = (uint8_t *)beams;
         const size_t foff = e->opt.layout == SB_LAYOUT_V1 ? 4 : 8;
-        sbt::parallel_ranges(B, 1 << 16, [&](size_t s0, size_t s1) {
-        for (size_t s = s0; s < s1; s++) {
+        sbt::parallel_ranges(sb_user_beams(e), 1 << 16, [&](size_t s0, size_t s1) {
+        for (size_t u = s0; u < s1; u++) {
             // every slot that was active at upload is written, dead ones with their last state
+            const uint32_t s = sb_user_slot(e, u);
             uint32_t c = e->h_copy_of_slot[s];
-            uint32_t idx = map_get(e, e->h_mapping.data(), (size_t)maxP + s);
+            uint32_t idx = map_get(e, e->h_mapping.data(), (size_t)maxP + u);
             uint8_t *rec = out + (size_t)idx * bstride, *f = rec + foff;
             const SbHostBeam &h = e->h_beams[s];
             if (e->opt.layout == SB_LAYOUT_V1) {
@@ -1954,6 +2044,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "grid_classic_substeps") *value = e->grid_classic_substeps; // substeps run in the classic schedule (helper launch in front)
     else if (k == "grid_schedule") *value = sbk_grid_mode(e);               // 0 lagged, 1 classic: what the next substep would run
     else if (k == "grid_cells") *value = e->ncell;
+    else if (k == "uploads_edited") *value = e->uploads_edited; // plan-keeping uploads that removed beams (rewrite_scene_state)
     else if (k == "grid_builds") {
         *value = 0;
         if (e->d_grid_ctl) {
@@ -2035,7 +2126,7 @@ static sb_status sb_halo_configure_impl(sb_engine *e, const uint32_t *ghost_part
     const uint32_t maxP = e->opt.max_particles, maxB = e->opt.max_beams;
     std::vector<uint32_t> internal_of_index(maxP, 0xFFFFFFFFu), slot_of_beam(maxB, 0xFFFFFFFFu);
     for (uint32_t i = 0; i < e->P; i++) internal_of_index[e->h_pidx[i]] = i;
-    for (uint32_t s = 0; s < e->B; s++) slot_of_beam[map_get(e, e->h_mapping.data(), (size_t)maxP + s)] = s;
+    for (uint32_t u = 0; u < sb_user_beams(e); u++) slot_of_beam[map_get(e, e->h_mapping.data(), (size_t)maxP + u)] = sb_user_slot(e, u);
     auto translate = [](const uint32_t *src, uint32_t n, const std::vector<uint32_t> &table, std::vector<uint32_t> &dst) {
         dst.resize(n);
         for (uint32_t k = 0; k < n; k++) {

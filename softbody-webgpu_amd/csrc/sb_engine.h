@@ -134,6 +134,12 @@ struct sb_engine {
     uint32_t *d_live0 = nullptr;     // entry words (blocked) / endpoint words (tiled) / first endpoints (atomic) as uploaded
     size_t live_words = 0;
     uint32_t uploads_kept = 0;       // uploads that kept the plan (sb_info "uploads_kept")
+    // An upload that only REMOVED beams from the scene on the device keeps the plan too (sb_api.hip rewrite_scene_state): the
+    // engine's own slots stay those of the upload the plan was made for, the removed ones die on the device like beams a delete
+    // pass removed, and the caller's slots (0 .. beam count of the latest upload) map onto the engine's: h_user_slot[u], strictly
+    // increasing; empty = identity.  Every path that speaks the caller's slots goes through sb_user_slot() / sb_user_beams().
+    std::vector<uint32_t> h_user_slot;
+    uint32_t uploads_edited = 0;     // ... of them, uploads that removed beams (sb_info "uploads_edited")
 
     // device state
     SbParticleArrays part[2]{};

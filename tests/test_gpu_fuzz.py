@@ -256,7 +256,7 @@ def test_the_quiet_scenes_really_ran_blocked():
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(NGRID // 4, 1)))
 def test_random_upload_sequences_keep_or_replan(sb, oracle, seed):
     """One engine, a random sequence of uploads: the same topology with everything else changed (the plan is kept), the state just
-    read back (beams gone: planned again), another scene of the same capacity, the same buffers twice -- each followed by substeps
+    read back (beams gone: since r04 an edit that keeps the plan too), a cut of a few per cent of the beams, another scene of the same capacity, the same buffers twice -- each followed by substeps
     and frames and compared with a fresh oracle.  Collisions off (blocked plan) or on (tiling + hybrid), tiled or atomic path."""
     rng = np.random.default_rng(7000 + seed)
     mode = GRID if rng.integers(0, 2) else OFF
@@ -278,12 +278,22 @@ def test_random_upload_sequences_keep_or_replan(sb, oracle, seed):
     last_read = None
     kept_expected = 0
     for step in range(6):
-        what = int(rng.integers(0, 4)) if step else 0
-        if what == 1 and last_read is not None:
+        what = int(rng.integers(0, 5)) if step else 0
+        if what == 4 and cur.beam_count > 8:                   # an edit that cuts up to 6 % of the beams (r04: the plan is kept)
+            src = last_read if (last_read is not None and rng.integers(0, 2)) else cur
+            B, maxP = src.beam_count, src.max_particles
+            keep = rng.random(B) >= rng.uniform(0.0, 0.06)
+            recs = src.beams[src.mapping[maxP:maxP + B].astype(np.int64)][keep]
+            cur = src.copy()
+            idx = rng.permutation(src.max_beams)[:len(recs)] if rng.integers(0, 2) else np.arange(len(recs))
+            cur.beams[idx] = recs
+            cur.mapping[maxP:maxP + len(recs)] = idx
+            cur.beam_count = len(recs)
+        elif what == 1 and last_read is not None:
             cur = last_read                                   # what the engine returned last time (maybe fewer beams)
         elif what == 2:
             cur = fit(scenes[int(rng.integers(0, 2))][0])     # a scene from scratch
-        elif what == 3 or (what == 1 and last_read is None):
+        elif what in (3, 4) or (what == 1 and last_read is None):
             cur = cur.copy()                                  # same topology, everything that may move moved
             P, B = cur.particle_count, cur.beam_count
             cur.particles[:P, :2] += rng.uniform(-0.4, 0.4, (P, 2)).astype("f4")
@@ -311,14 +321,18 @@ def test_random_upload_sequences_keep_or_replan(sb, oracle, seed):
         assert np.array_equal(got.mapping, exp.mapping)
         last_read = got
     UPLOADS_KEPT[seed] = eng.info("uploads_kept")
+    UPLOADS_EDITED[seed] = eng.info("uploads_edited")
     eng.destroy()
 
 
 UPLOADS_KEPT = {}
+UPLOADS_EDITED = {}
 
 
 def test_some_of_those_uploads_kept_their_plan():
     if not UPLOADS_KEPT:
         pytest.skip("the upload-sequence cases did not run in this session")
-    print("upload sequences: %d uploads kept the plan in %d cases" % (sum(UPLOADS_KEPT.values()), len(UPLOADS_KEPT)))
+    print("upload sequences: %d uploads kept the plan in %d cases, %d of them with beams removed" % (sum(UPLOADS_KEPT.values()), len(UPLOADS_KEPT),
+                                                                                             sum(UPLOADS_EDITED.values())))
     assert sum(UPLOADS_KEPT.values()) >= len(UPLOADS_KEPT) // 2
+    assert len(UPLOADS_KEPT) < 8 or sum(UPLOADS_EDITED.values()) >= 2

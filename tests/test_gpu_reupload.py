@@ -2,7 +2,10 @@
 every snapshot load): the engine keeps its plan -- bisection, rings, entry lists, material rows, the hash's arrays -- and only
 state travels (csrc/sb_api.hip rewrite_scene_state).  The second run must be, bit for bit, what a new engine would have done:
 moved particles, changed target / last lengths, beams that the FIRST run's delete passes removed alive again, flags and masks as
-uploaded.  Anything that touches the topology (an endpoint, a rest length, a material, a count, the mapping) plans again."""
+uploaded.  Anything that touches the topology (an endpoint, a rest length, a material, the mapping, more beams) plans again --
+except an upload that only REMOVED beams (an editor's cut, a snapshot taken after beams broke: engineMapping.ts:500-518 writes the
+beams that are left in their old order), which keeps the plan too: the engine's own slots stay, the removed beams die on the
+device like beams a delete pass removed, the caller's slots map onto the engine's."""
 import numpy as np
 import pytest
 
@@ -72,13 +75,15 @@ def test_same_topology_keeps_the_plan(sb, oracle, mode, path, distinct):
         again, _ = play(eng, ref, second)
         assert eng.info("uploads_kept") == k
         assert_same(again, exp2, "same upload again")
-    # 3. what the first run read back (beams gone, mapping compacted): a different topology, planned again
+    # 3. what the first run read back (beams gone, the mapping compacted by the delete passes): the same scene minus a few beams --
+    # since r04 that keeps the plan as well (test_removed_beams_keep_the_plan), unless the run broke more than an eighth of them
+    edit = first.beam_count - got.beam_count <= first.beam_count // 8
     got3, exp3 = play(eng, ref, got)
-    assert eng.info("uploads_kept") == 3
+    assert eng.info("uploads_kept") == (4 if edit else 3) and eng.info("uploads_edited") == (1 if edit else 0)
     assert_same(got3, exp3, "read-back state uploaded")
-    # ... and THAT topology twice in a row is kept again
+    # ... and THAT topology again is kept either way
     got4, exp4 = play(eng, ref, moved(got, 9))
-    assert eng.info("uploads_kept") == 4
+    assert eng.info("uploads_kept") == (5 if edit else 4)
     assert_same(got4, exp4, "read-back topology, moved")
     eng.destroy()
 
@@ -157,3 +162,135 @@ def test_second_upload_of_config2_is_quick(sb):
     assert np.array_equal(a.particles.view("u4"), b.particles.view("u4")) and a.beams.tobytes() == b.beams.tobytes()
     print("re-uploads that keep the plan: %s ms" % ", ".join("%.1f" % x for x in t))
     assert min(t) <= 30.0, t
+
+
+def without(buf, keep, *, shuffle_mapping=None):
+    """`buf` with only the beams keep[] of its first beam_count slots, renumbered in order (what BufferMapper.writeState leaves of a
+    scene after removeBeam calls).  shuffle_mapping: a seed -- the records then sit at permuted data indices."""
+    out = buf.copy()
+    B, maxP = buf.beam_count, buf.max_particles
+    recs = buf.beams[buf.mapping[maxP:maxP + B].astype(np.int64)][keep]
+    n = len(recs)
+    idx = np.arange(n)
+    if shuffle_mapping is not None:
+        idx = np.random.default_rng(shuffle_mapping).permutation(buf.max_beams)[:n]
+    out.beams[idx] = recs
+    out.mapping[maxP:maxP + n] = idx
+    out.beam_count = n
+    return out
+
+
+@pytest.mark.parametrize("mode,path,kw", [(OFF, TILED, {}), (OFF, TILED, {"block_substeps": 1}), (GRID, TILED, {}), (GRID, ATOMIC, {}),
+                                           (OFF, ATOMIC, {})])
+def test_removed_beams_keep_the_plan(sb, oracle, mode, path, kw):
+    first = breaking_lattice(sb)
+    eng = sb.Engine(bounds_size=BOUNDS, layout=2, max_particles=first.max_particles, max_beams=first.max_beams, collision_mode=mode, path=path, **kw)
+    ref = oracle.OracleEngine(BOUNDS, 10.0, 64, 2, mode, threads=8)
+    got, exp = play(eng, ref, first, frames=1)
+    assert_same(got, exp, "first upload")
+    rng = np.random.default_rng(11)
+    # 1. an edit that cuts 1 % of the beams (and moves everything): plan kept, the cut beams gone from counts, records and mapping
+    B = first.beam_count
+    keep = rng.random(B) >= 0.01
+    second = without(moved(first, 7), keep)
+    assert 0 < B - second.beam_count < B // 8
+    got2, exp2 = play(eng, ref, second)
+    assert eng.info("uploads_kept") == 1 and eng.info("uploads_edited") == 1
+    assert exp2.beam_count < second.beam_count, "the run must break beams on top of the cut ones"
+    assert_same(got2, exp2, "1 % of the beams cut")
+    assert eng.counts() == (second.particle_count, exp2.beam_count)
+    # 2. the same buffers again (same topology as the engine's caller-side view): kept, not an edit
+    again, _ = play(eng, ref, second)
+    assert eng.info("uploads_kept") == 2 and eng.info("uploads_edited") == 1
+    assert_same(again, exp2, "the cut scene again")
+    # 3. a second cut on top of the first, the records at shuffled data indices this time
+    keep2 = rng.random(second.beam_count) >= 0.02
+    keep2[:3] = False
+    keep2[-2:] = False
+    third = without(moved(second, 3), keep2, shuffle_mapping=5)
+    got3, exp3 = play(eng, ref, third)
+    assert eng.info("uploads_kept") == 3 and eng.info("uploads_edited") == 2
+    assert_same(got3, exp3, "a second cut, shuffled mapping")
+    # 4. what that run read back (its own breaks on top): still only removals
+    got4, exp4 = play(eng, ref, got3)
+    assert eng.info("uploads_kept") == 4 and eng.info("uploads_edited") == 3
+    assert_same(got4, exp4, "the read-back of a cut scene")
+    # 5. a beam comes back (the first upload again): more beams than the engine's caller-side view -- planned again
+    got5, exp5 = play(eng, ref, first, frames=1)
+    assert eng.info("uploads_kept") == 4
+    assert_same(got5, exp5, "the whole scene again")
+    eng.destroy()
+
+
+def test_removed_beams_in_the_reference_layout(sb, oracle):
+    first = breaking_lattice(sb, layout=1)
+    eng = sb.Engine(bounds_size=BOUNDS, layout=1, max_particles=first.max_particles, max_beams=first.max_beams, collision_mode=GRID)
+    ref = oracle.OracleEngine(BOUNDS, 10.0, 64, 1, GRID, threads=8)
+    got, exp = play(eng, ref, first, frames=1)
+    assert_same(got, exp, "layout 1, first upload")
+    keep = np.random.default_rng(2).random(first.beam_count) >= 0.03
+    second = without(moved(first, 4), keep)
+    got2, exp2 = play(eng, ref, second)
+    assert eng.info("uploads_kept") == 1 and eng.info("uploads_edited") == 1
+    assert_same(got2, exp2, "layout 1, 3 % of the beams cut")
+    # not a subsequence (two of the beams that are left trade places): planned again
+    third = second.copy()
+    m, a, b = third.mapping, third.max_particles + 5, third.max_particles + 400
+    m[a], m[b] = m[b], m[a]
+    third.beam_count = third.beam_count - 1
+    got3, exp3 = play(eng, ref, third)
+    assert eng.info("uploads_kept") == 1
+    assert_same(got3, exp3, "layout 1, cut and reordered")
+    eng.destroy()
+
+
+def test_an_edit_of_config2_is_quick(sb):
+    """BASELINE config 2 with 1 % of its 3 M beams cut (<= 30 ms against ~125 ms for an upload that plans); the run
+    after it equals the run of a new engine given the same buffers."""
+    import time
+    buf = sb.scenes.lattice_buffers(1000, 1000, d=30.0, origin=(1000.0, 1000.0), jitter=1.0, layout=2)
+    eng = sb.Engine(bounds_size=32000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=OFF)
+    eng.write_buffers(buf)
+    eng.step(14)
+    state = eng.load_buffers(buf.copy())
+    keep = np.random.default_rng(1).random(buf.beam_count) >= 0.01
+    cut = without(state, keep)
+    t0 = time.perf_counter()
+    eng.write_buffers(cut)
+    ms = (time.perf_counter() - t0) * 1e3
+    assert eng.info("uploads_kept") == 1 and eng.info("uploads_edited") == 1
+    eng.step(21)
+    a = eng.load_buffers(cut.copy())
+    eng.destroy()
+    new = sb.Engine(bounds_size=32000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=OFF)
+    new.write_buffers(cut)
+    new.step(21)
+    b = new.load_buffers(cut.copy())
+    new.destroy()
+    assert np.array_equal(a.particles.view("u4"), b.particles.view("u4")) and a.beams.tobytes() == b.beams.tobytes()
+    assert np.array_equal(a.mapping, b.mapping) and a.beam_count == b.beam_count == cut.beam_count
+    print("upload with 1 %% of the beams cut, plan kept: %.1f ms" % ms)
+    assert ms <= 30.0, ms
+
+
+def test_removed_beams_under_blocked_launches_of_the_hash(sb, oracle):
+    """A quiet lattice in the default collision mode runs blocked launches under the hash (the hybrid plan beside the tiling); beams
+    an upload removed have to die in THAT plan as well (k_hybrid_sync_dead, from the tiled layout's endpoint words)."""
+    buf = sb.scenes.lattice_buffers(128, 96, d=30.0, origin=(300.0, 900.0), jitter=1.0, layout=2, velocity=(0.4, -1.0))
+    eng = sb.Engine(bounds_size=6000.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=GRID)
+    ref = oracle.OracleEngine(6000.0, 10.0, 64, 2, GRID, threads=16)
+    eng.write_buffers(buf); ref.write_buffers(buf)
+    eng.step(150); ref.step(150)
+    state = eng.load_buffers(buf.copy())
+    assert_same(state, ref.load_buffers(buf.copy()), "before the cut")
+    before = eng.info("hybrid_substeps")
+    assert before >= 60
+    cut = without(state, np.random.default_rng(3).random(buf.beam_count) >= 0.02)
+    eng.write_buffers(cut); ref.write_buffers(cut)
+    assert eng.info("uploads_kept") == 1 and eng.info("uploads_edited") == 1
+    for n in (150, 64):
+        eng.step(n); ref.step(n)
+    got, exp = eng.load_buffers(cut.copy()), ref.load_buffers(cut.copy())
+    assert eng.info("hybrid_substeps") - before >= 100, "the run after the cut must go blocked again"
+    assert_same(got, exp, "2 % of the beams cut, hybrid")
+    eng.destroy()
