@@ -547,9 +547,9 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
         // break flags of its own (merged into the tiled layout's on the way back), the maps between the two layouts, the
         // running state of a tracked run
         SB_TRY(dev_alloc(e, &k.d_broken, (B + 31) / 32));
-        SB_TRY(dev_alloc(e, &k.d_broken_new, (B + 31) / 32));
+        for (int b = 0; b < 2; b++) SB_TRY(dev_alloc(e, &k.d_broken_new[b], (B + 31) / 32));
         SB_HIP(e, hipMemsetAsync(k.d_broken, 0, std::max<size_t>((B + 31) / 32, 1) * 4, e->stream));
-        SB_HIP(e, hipMemsetAsync(k.d_broken_new, 0, std::max<size_t>((B + 31) / 32, 1) * 4, e->stream));
+        for (int b = 0; b < 2; b++) SB_HIP(e, hipMemsetAsync(k.d_broken_new[b], 0, std::max<size_t>((B + 31) / 32, 1) * 4, e->stream));
         sbt::uvec<uint32_t> copy_of_g(B), g_of_copy(tiled_copy_slot->size());
         sbt::parallel_ranges(B, 1 << 16, [&](size_t g0, size_t g1) {
             for (size_t g = g0; g < g1; g++) copy_of_g[g] = (*tiled_copy_of_slot)[bl.beam_slot[g]];
@@ -559,10 +559,11 @@ static sb_status upload_blocked(sb_engine *e, const SbBlocking &bl, const SbHost
         });
         SB_TRY(dev_upload(e, &k.d_copy_of_g, copy_of_g));
         SB_TRY(dev_upload(e, &k.d_g_of_copy, g_of_copy));
-        SB_TRY(dev_alloc(e, &k.d_q, 1));
-        SB_TRY(dev_alloc(e, &k.d_dmax, 3 * (size_t)T));
-        SB_HIP(e, hipMemsetAsync(k.d_dmax, 0, std::max<size_t>(3 * (size_t)T, 1) * 4, e->stream));
-        SB_HIP(e, hipMemsetAsync(k.d_q, 0, sizeof(SbHybridCtl), e->stream));
+        SB_TRY(dev_alloc(e, &k.d_q, 2));
+        SB_TRY(dev_alloc(e, &k.d_hslots, 3 * 65 * 4));
+        SB_HIP(e, hipMemsetAsync(k.d_hslots, 0, 3 * 65 * 16, e->stream));
+        SB_HIP(e, hipMemsetAsync(k.d_q, 0, 2 * sizeof(SbHybridCtl), e->stream));
+        k.qpar = k.seq = k.run_launches = k.k_prev = 0;
         k.synced_delete_gen = 0;
         k.slow_chunk = 0;
         k.slow_left = 0;
@@ -1563,9 +1564,10 @@ static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
 //   look   (stream sync + a few words back): lists all empty? no rebuild pending? at least half the skin left?
 //   no  -> substep by substep for a stretch that doubles while the answer stays no (a pile never pays more than a few looks),
 //          then look again;
-//   yes -> beam state into the blocked layout, a run of tracked launches (k_substep_blocked<TRACK> + k_hybrid_validate each:
-//          the launch measures what its particles move, the validation adds it to the bound; one over the skin raises a
-//          flag on the device and everything queued behind returns at once), state back into the tiled layout, the hash's
+//   yes -> beam state into the blocked layout, a run of tracked launches (k_substep_blocked<TRACK>: the launch measures what
+//          its particles move, the launch behind it -- k_hybrid_validate behind the last one -- adds that to the bound in its
+//          prologue; one over the skin raises a flag on the device and everything queued behind returns at once, having
+//          written nothing), state back into the tiled layout, the hash's
 //          bookkeeping (bound, drift, age) brought up to date; a launch that went over is simply not counted -- the buffers it
 //          read are intact (everything is double-buffered) -- and its substeps are redone one by one, where the hash gets rebuilt.
 // Every other entry point sees the tiled layout only.  Bit-exact by construction: a launch counts only if no contact could
@@ -1702,12 +1704,12 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
             q.fail_at = fail_every - 1u - (uint32_t)((h.launches_ok + h.launches_failed) % fail_every); // (tests: a roll-back every so many launches)
         SbHybridCtl *pin = (SbHybridCtl *)(e->dev_err + 64);
         *pin = q;
-        SB_HIP(e, hipMemcpyAsync(h.d_q, pin, sizeof q, hipMemcpyHostToDevice, e->stream));
+        SB_HIP(e, hipMemcpyAsync(h.d_q + h.qpar, pin, sizeof q, hipMemcpyHostToDevice, e->stream)); // (the block the run's first launch reads)
         sbk_hybrid_to_blocked(e);
         const uint32_t cur0 = e->cur, bcur0 = h.cur;
         const uint64_t done0 = e->substeps_done;
         sbk_hybrid_launch(e, ks, count, aux_last);
-        SB_HIP(e, hipMemcpyAsync(pin, h.d_q, sizeof q, hipMemcpyDeviceToHost, e->stream));
+        SB_HIP(e, hipMemcpyAsync(pin, h.d_q + h.qpar, sizeof q, hipMemcpyDeviceToHost, e->stream)); // (... and the one its last validation wrote)
         // (the run is a few hundred microseconds to a few milliseconds of kernels, known in advance: poll for twice that)
         SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)planned * (int64_t)(20u + e->P / 25000u), 8000)));
         q = *pin;

@@ -75,23 +75,48 @@ struct SbBlockedState {
 // of each of its particles); k_hybrid_validate adds the launch's maximum to the hash's running bound and raises *bad when
 // that exceeds the skin -- the launches queued behind then return at once and the host redoes the block substep by substep.
 struct SbTrack {
-    const SbHybridCtl *q; // bad (sticky: return at once), cx / cy (the drift this launch measures against: the mean displacement
-                          // in the last substep of the launch before, by one sample particle per tile)
-    uint32_t *dmax;       // [ntiles] displacement sums, then [2 ntiles] the samples (dx, dy of each tile's first particle, last substep)
-    uint32_t ntiles;
-    uint32_t *any_broken; // raised when the launch flags a beam: its flags sit in a mask of their own until the launch is validated
+    // r04: a tracked launch VALIDATES THE LAUNCH BEFORE IT in its own prologue (the separate k_hybrid_validate launch behind every
+    // tracked launch cost 4.6 us per six substeps; only the last launch of a run still gets one).  What a launch leaves for its
+    // successor: 64 slots {largest displacement sum by atomic max, the sample (dx, dy) of tiles 0 .. 63} + one flag word (a beam was
+    // flagged), triple buffered by launch number like the spatial hash's slots (sb_physics.h SbGridStep); the running state
+    // (SbHybridCtl) in two blocks: every workgroup reads `q_in` and computes the verdict for itself -- one wave, 64 loads -- and
+    // workgroup 0 writes the updated block `q_out` for the next launch.  Nothing is communicated inside a launch.
+    const SbHybridCtl *q_in;
+    SbHybridCtl *q_out;
+    const float4 *slots_prev; // what the launch before left (nullptr: nothing to validate -- the first launch of a run)
+    float4 *slots_out, *slots_zero;
+    uint32_t k_prev;          // substeps of the launch before
+    uint32_t *broken_prev;    // its break flags, waiting for the verdict (merged into `broken_ok` by the tiles that own the beams)
+    uint32_t *broken_ok;
 };
+#define SB_HY_SLOTS 64u  // + one flag entry behind them
 template <int MAT, bool AUX, bool PLAIN, bool TRACK>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
     const uint32_t *__restrict__ acc_flag_r, uint32_t *acc_flag_w, SbTrack tr)
 {
-    if (TRACK && __hip_atomic_load(&tr.q->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return; // (uniform: every lane reads the one word)
     float moved_sum = 0.0f; // TRACK: sum over the substeps of this thread's largest drift-relative displacement
     float track_cx = 0.0f, track_cy = 0.0f;
+    bool prev_broke = false; // TRACK: the launch before flagged beams, and it counts: its flags are merged below
+    // TRACK: what the verdict on the launch before needs is REQUESTED here and consumed behind the acceleration / plastic flags
+    // below, which are a trip to the L2 of their own anyway (consumed at once, the verdict put a second trip in front of every
+    // workgroup's first request: +3.8 us per launch)
+    uint32_t hy_wv = 0u, hy_flagged = 0u;
+    float4 hy_sl = make_float4(0.f, 0.f, 0.f, 0.f);
     if (TRACK) {
-        track_cx = __uint_as_float(__hip_atomic_load((const uint32_t *)&tr.q->cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        track_cy = __uint_as_float(__hip_atomic_load((const uint32_t *)&tr.q->cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // the verdict on the launch before this one, by every workgroup for itself (uniform: everybody reads the same words -- through
+        // the VECTOR path, a word per lane: the launch before wrote them, and the scalar cache is not refreshed between launches)
+        const uint32_t lane = threadIdx.x & 63u, nw = (uint32_t)(sizeof(SbHybridCtl) / 4u);
+        uint32_t wi = lane < nw ? lane : 0u;
+        asm volatile("" : "+v"(wi));
+        hy_wv = ((const uint32_t *)tr.q_in)[wi];
+        if (tr.slots_prev) {
+            uint32_t si = lane, fi = SB_HY_SLOTS;
+            asm volatile("" : "+v"(si), "+v"(fi));
+            hy_sl = tr.slots_prev[si];
+            hy_flagged = __float_as_uint(tr.slots_prev[fi].x);
+        }
+        if (blockIdx.x == 0u && threadIdx.x <= SB_HY_SLOTS) tr.slots_zero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // static LDS layout: every address below is a register plus an immediate offset
     __shared__ float2 s_pos[SB_BK_CAP];
@@ -123,7 +148,61 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         }
     }
     const bool nb_plastic = __builtin_amdgcn_ballot_w64(nb_plastic_lane) != 0ull;
+    if (TRACK) {
+        const uint32_t nw = (uint32_t)(sizeof(SbHybridCtl) / 4u);
+        SbHybridCtl q;
+        {
+            uint32_t *qw = (uint32_t *)&q;
+#pragma unroll
+            for (uint32_t i = 0; i < nw; i++) qw[i] = (uint32_t)__builtin_amdgcn_readlane((int)hy_wv, (int)i);
+        }
+        if (q.bad == 0u && tr.slots_prev) {
+            float m = hy_sl.x, sx = hy_sl.y, sy = hy_sl.z;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { // (a butterfly: the same sums in every wave of every workgroup)
+                m = fmaxf(m, __shfl_xor(m, off, 64));
+                sx += __shfl_xor(sx, off, 64);
+                sy += __shfl_xor(sy, off, 64);
+            }
+            m = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
+            sx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sx)));
+            sy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sy)));
+            const float D = q.D + m;
+            const bool ok = D <= q.skin && q.done != q.fail_at; // (NaN-safe; fail_at: the forced roll-back of the tests)
+            if (!ok) {
+                q.bad = 1u;
+            } else {
+                const float ns = (float)min(bp.ntiles, SB_HY_SLOTS);
+                float mx = sb_div(sx, ns), my = sb_div(sy, ns); // (the drift this launch measures against: any estimate keeps the bound valid)
+                if (!(sb_abs(mx) < 1.0e30f) || !(sb_abs(my) < 1.0e30f)) mx = my = 0.0f;
+                q.D = D;
+                q.Cx += (float)tr.k_prev * q.cx; // (the drift the launch before measured against)
+                q.Cy += (float)tr.k_prev * q.cy;
+                q.cx = mx;
+                q.cy = my;
+                q.done += 1u;
+                q.substeps += tr.k_prev;
+                prev_broke = __builtin_amdgcn_readfirstlane(hy_flagged) != 0u;
+            }
+        }
+        if (blockIdx.x == 0u && threadIdx.x == 0u) *tr.q_out = q;
+        if (q.bad != 0u) return; // (uniform; nothing has been written: the launches behind return the same way)
+        track_cx = q.cx;
+        track_cy = q.cy;
+    }
 
+    if (TRACK && prev_broke) { // (rare) the flags the launch before raised on THIS tile's beams count now: into the mask the way back reads
+        for (uint32_t wd = (b0 >> 5) + tid; wd <= ((b0 + n_ownb) >> 5) && n_ownb; wd += SB_BK_T) {
+            const uint32_t lo = max(b0, wd * 32u), hi = min(b0 + n_ownb, wd * 32u + 32u);
+            if (hi <= lo) continue;
+            const uint32_t mask = (hi - lo == 32u ? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u)) << (lo - wd * 32u);
+            const uint32_t bits = __hip_atomic_load(&tr.broken_prev[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask;
+            if (bits) {
+                atomicOr(&tr.broken_ok[wd], bits);
+                atomicAnd(&tr.broken_prev[wd], ~bits);
+            }
+        }
+    }
     // ---- load, in two waves of requests: (1) everything whose address follows from the tile tables -- the INDICES of the halo
     // and of the halo entries' states first (the gathers wait for them, and a wait for the k-th request is a wait for the k - 1
     // before it), then own particles, own beam states and the entry words -- all issued back to back; (2) the gathers the
@@ -426,8 +505,10 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                     const float m = fmaxf(sb_abs(ddx - track_cx), sb_abs(ddy - track_cy)) * 1.4142137f;
                     moved_now = fmaxf(moved_now, m < 1.0e30f ? m : 1.0e30f); // (NaN reads as huge)
                     if (i == 0 && tid == 0 && s == k_run) { // this tile's sample for the next launch's drift estimate
-                        __hip_atomic_store(&tr.dmax[tr.ntiles + 2u * tile], __float_as_uint(sb_abs(ddx) < 1.0e30f ? ddx : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&tr.dmax[tr.ntiles + 2u * tile + 1u], __float_as_uint(sb_abs(ddy) < 1.0e30f ? ddy : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (tile < SB_HY_SLOTS) { // (the sample of tiles 0 .. 63: the slot's y and z, which nobody else writes)
+                            __hip_atomic_store((uint32_t *)&tr.slots_out[tile].y, __float_as_uint(sb_abs(ddx) < 1.0e30f ? ddx : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((uint32_t *)&tr.slots_out[tile].z, __float_as_uint(sb_abs(ddy) < 1.0e30f ? ddy : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
                 s_pos[q] = particle.p;
@@ -479,7 +560,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                 sb_store_wt(&bs.last_w[b0 + j], ls[i]);
                 if ((brk >> i) & 1u) {
                     atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
-                    if (TRACK) __hip_atomic_store(tr.any_broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (TRACK) __hip_atomic_store((uint32_t *)&tr.slots_out[SB_HY_SLOTS].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
                 // a beam removed by a delete pass keeps its last state, which still has to travel to the other buffer: load,
@@ -505,73 +586,56 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
         if (tid == 0) {
             float b = 0.0f;
             for (uint32_t v = 0; v < SB_BK_T / 64u; v++) b = fmaxf(b, s_moved[v]);
-            __hip_atomic_store(&tr.dmax[tile], __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (sums are >= 0 and never NaN: their bit patterns order like the numbers)
+            (void)__hip_atomic_fetch_max((uint32_t *)&tr.slots_out[tile % SB_HY_SLOTS].x, __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-// after every tracked launch: the largest displacement sum of any tile joins the bound
-__global__ __launch_bounds__(1024) void k_hybrid_validate(const uint32_t *__restrict__ dmax, uint32_t ntiles, SbHybridCtl *q, uint32_t k,
-                                                          uint32_t *broken_new, uint32_t *broken_ok, uint32_t nwords)
+// behind the LAST tracked launch of a run (every other launch is validated by its successor's prologue, SbTrack): the same verdict
+// from the same slots, the running state into the block the host reads, the launch's break flags kept or dropped
+__global__ __launch_bounds__(64) void k_hybrid_validate(const float4 *__restrict__ slots, uint32_t ntiles, const SbHybridCtl *q_in, SbHybridCtl *q_out,
+                                                        uint32_t k, uint32_t *broken_new, uint32_t *broken_ok, uint32_t nwords)
 {
-    __shared__ float s_m[16], s_x[16], s_y[16];
-    __shared__ uint32_t s_ok;
-    if (__hip_atomic_load(&q->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    float m = 0.0f, sx = 0.0f, sy = 0.0f;
-    for (uint32_t i = threadIdx.x; i < ntiles; i += 1024u) {
-        m = fmaxf(m, __uint_as_float(__hip_atomic_load(&dmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        sx += __uint_as_float(__hip_atomic_load(&dmax[ntiles + 2u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        sy += __uint_as_float(__hip_atomic_load(&dmax[ntiles + 2u * i + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
+    const uint32_t lane = threadIdx.x;
+    const float4 sl = slots[lane];
+    const bool flagged = __float_as_uint(slots[SB_HY_SLOTS].x) != 0u;
+    SbHybridCtl q = *q_in;
+    bool ok = false;
+    if (q.bad == 0u) {
+        float m = sl.x, sx = sl.y, sy = sl.z;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmaxf(m, __shfl_xor(m, off, 64));
-        sx += __shfl_xor(sx, off, 64);
-        sy += __shfl_xor(sy, off, 64);
-    }
-    if ((threadIdx.x & 63u) == 0u) {
-        s_m[threadIdx.x >> 6] = m;
-        s_x[threadIdx.x >> 6] = sx;
-        s_y[threadIdx.x >> 6] = sy;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float b = 0.0f, tx = 0.0f, ty = 0.0f;
-        for (int v = 0; v < 16; v++) {
-            b = fmaxf(b, s_m[v]);
-            tx += s_x[v];
-            ty += s_y[v];
+        for (int off = 32; off > 0; off >>= 1) { // (the butterfly of the launches' own prologues: the same numbers)
+            m = fmaxf(m, __shfl_xor(m, off, 64));
+            sx += __shfl_xor(sx, off, 64);
+            sy += __shfl_xor(sy, off, 64);
         }
-        const float D = q->D + b;
-        const bool ok = D <= q->skin && q->done != q->fail_at; // (NaN-safe; fail_at: the forced roll-back of the tests)
-        s_ok = ok ? 1u : 0u;
+        const float D = q.D + m;
+        ok = D <= q.skin && q.done != q.fail_at;
         if (!ok) {
-            __hip_atomic_store(&q->bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q.bad = 1u;
         } else {
-            q->D = D;
-            q->Cx += (float)k * q->cx; // (the drift the launch measured against ...)
-            q->Cy += (float)k * q->cy;
-            float mx = tx / (float)ntiles, my = ty / (float)ntiles; // (... and the one the next launch will: any estimate keeps the bound valid)
+            const float ns = (float)min(ntiles, SB_HY_SLOTS);
+            float mx = sb_div(sx, ns), my = sb_div(sy, ns);
             if (!(sb_abs(mx) < 1.0e30f) || !(sb_abs(my) < 1.0e30f)) mx = my = 0.0f;
-            __hip_atomic_store((uint32_t *)&q->cx, __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store((uint32_t *)&q->cy, __float_as_uint(my), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q->done += 1u;
-            q->substeps += k;
+            q.D = D;
+            q.Cx += (float)k * q.cx;
+            q.Cy += (float)k * q.cy;
+            q.cx = mx;
+            q.cy = my;
+            q.done += 1u;
+            q.substeps += k;
         }
     }
-    // break flags the launch raised (almost never any): kept if the launch counts, dropped if not
-    if (__hip_atomic_load(&q->any_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        __syncthreads();
-        const bool ok = s_ok != 0u;
-        for (uint32_t i = threadIdx.x; i < nwords; i += 1024u) {
+    if (lane == 0u) *q_out = q;
+    if (flagged) // break flags the launch raised (almost never any): kept if the launch counts, dropped if not
+        for (uint32_t i = lane; i < nwords; i += 64u) {
             const uint32_t bits = broken_new[i];
             if (bits) {
                 if (ok) broken_ok[i] |= bits;
                 broken_new[i] = 0u;
             }
         }
-        if (threadIdx.x == 0) q->any_broken = 0u;
-    }
 }
 
 // beam state between the two device layouts of an SB_COLLIDE_GRID engine that can run blocked (sb_api.hip hybrid_step): the
@@ -711,8 +775,24 @@ static void launch_one(sb_engine *e, SbBlockedDev &bk, uint32_t k, bool aux, boo
     SbBlockedState bs{bk.d_target[bk.cur], bk.d_last[bk.cur], bk.d_target[bk.cur ^ 1u], bk.d_last[bk.cur ^ 1u], bk.d_strain, bk.d_stress,
                       bk.d_broken, bk.d_plastic[bk.cur], bk.d_plastic[bk.cur ^ 1u]};
     SbParticleArrays r = e->part[e->cur], w = e->part[e->cur ^ 1];
-    SbTrack tr{bk.d_q, bk.d_dmax, bk.ntiles, bk.d_q ? &bk.d_q->any_broken : nullptr};
-    if (track) bs.broken = bk.d_broken_new; // (validated into bk.d_broken by k_hybrid_validate)
+    SbTrack tr{};
+    if (track) { // (launch number bk.seq: its slots, the block it reads and the one it writes, its own mask of break flags)
+        float4 *slots = (float4 *)bk.d_hslots;
+        const uint32_t set = bk.seq % 3u, stride = SB_HY_SLOTS + 1u;
+        tr.q_in = bk.d_q + bk.qpar;
+        tr.q_out = bk.d_q + (bk.qpar ^ 1u);
+        tr.slots_prev = bk.run_launches ? slots + ((bk.seq + 2u) % 3u) * stride : nullptr;
+        tr.slots_out = slots + set * stride;
+        tr.slots_zero = slots + ((bk.seq + 1u) % 3u) * stride;
+        tr.k_prev = bk.k_prev;
+        tr.broken_prev = bk.d_broken_new[(bk.seq + 1u) & 1u];
+        tr.broken_ok = bk.d_broken;
+        bs.broken = bk.d_broken_new[bk.seq & 1u]; // (merged into bk.d_broken by the launch behind it, or by k_hybrid_validate)
+        bk.qpar ^= 1u;
+        bk.seq++;
+        bk.run_launches++;
+        bk.k_prev = k;
+    }
 #define SB_LAUNCH_B(M, A, PL, TR)                                                                                            \
     k_substep_blocked<M, A, PL, TR><<<bk.ntiles, SB_BK_T, bk.lds_bytes, e->stream>>>(r, w, bp, bs, k, e->consts, e->prm,        \
                                                                                     e->d_acc_flag[e->cur], e->d_acc_flag[e->cur ^ 1], tr)
@@ -795,7 +875,8 @@ void sbk_hybrid_to_blocked(sb_engine *e)
                                                          h.mat_mode == 1 ? h.d_ent_length : nullptr, h.d_mat, h.d_target[h.cur],
                                                          h.d_target[h.cur ^ 1u], h.d_last[h.cur], h.d_plastic[0], h.d_plastic[1]);
     (void)hipMemsetAsync(h.d_broken, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
-    (void)hipMemsetAsync(h.d_broken_new, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
+    for (int b = 0; b < 2; b++) (void)hipMemsetAsync(h.d_broken_new[b], 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
+    (void)hipMemsetAsync(h.d_hslots, 0, 3u * (SB_HY_SLOTS + 1u) * sizeof(float4), e->stream); // (a run starts from clean slots whatever ended the one before)
 }
 void sbk_hybrid_to_tiled(sb_engine *e, bool aux)
 {
@@ -810,9 +891,13 @@ void sbk_hybrid_launch(sb_engine *e, const uint32_t *ks, uint32_t count, bool au
 {
     SbBlockedDev &h = e->hy;
     if (h.mat_mode == 1) allow_large_lds(e->device);
-    for (uint32_t i = 0; i < count; i++) {
-        launch_one(e, h, ks[i], aux_last && i + 1 == count, true);
-        k_hybrid_validate<<<1, 1024, 0, e->stream>>>(h.d_dmax, h.ntiles, h.d_q, ks[i], h.d_broken_new, h.d_broken, cdiv_b(h.nbeams, 32));
+    h.run_launches = 0; // (the first launch of a run has nobody to validate)
+    for (uint32_t i = 0; i < count; i++) launch_one(e, h, ks[i], aux_last && i + 1 == count, true);
+    if (count) { // ... and the last one nobody behind it: the verdict on it by a launch of its own, into the block the host reads
+        const uint32_t last = h.seq - 1u;
+        k_hybrid_validate<<<1, 64, 0, e->stream>>>((const float4 *)h.d_hslots + (last % 3u) * (SB_HY_SLOTS + 1u), h.ntiles, h.d_q + h.qpar,
+                                                  h.d_q + (h.qpar ^ 1u), ks[count - 1], h.d_broken_new[last & 1u], h.d_broken, cdiv_b(h.nbeams, 32));
+        h.qpar ^= 1u;
     }
 }
 

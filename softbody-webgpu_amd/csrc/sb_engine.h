@@ -60,7 +60,7 @@ struct SbHybridCtl {
     float cx, cy, skin;  // the drift every launch measures against; the budget
     uint32_t bad, done;  // sticky: a launch went over the budget (its result is discarded); launches that stayed within it
     uint32_t substeps;   // ... and the substeps they advanced
-    uint32_t any_broken; // the launch in flight flagged a beam (its flags wait in a mask of their own for the verdict)
+    uint32_t pad_;       // (r03: any_broken -- the flag rides behind the launch's slots now, sb_blocked.hip SbTrack)
     uint32_t fail_at;    // tests: the launch with this number fails whatever it measured (0xFFFFFFFF: none)
 };
 
@@ -88,10 +88,11 @@ struct SbBlockedDev {
     float *d_strain = nullptr, *d_stress = nullptr;
     uint32_t *d_broken = nullptr;
     // hybrid only
-    uint32_t *d_broken_new = nullptr; // break flags of the tracked launch in flight
+    uint32_t *d_broken_new[2] = {nullptr, nullptr}; // break flags of the tracked launches in flight, by launch number parity (sb_blocked.hip SbTrack)
     uint32_t *d_copy_of_g = nullptr, *d_g_of_copy = nullptr; // blocked beam -> a tiled copy of it; tiled copy -> blocked beam
     SbHybridCtl *d_q = nullptr;
-    uint32_t *d_dmax = nullptr;       // per tile: largest displacement sum of the last tracked launch (float bits)
+    float *d_hslots = nullptr;        // what a tracked launch leaves for the launch that validates it: 3 sets of 64 slots + a flag entry (float4 each)
+    uint32_t qpar = 0, seq = 0, run_launches = 0, k_prev = 0; // which of the two SbHybridCtl blocks is current; launch number; launches of the run so far; depth of the last
     uint32_t synced_delete_gen = 0;   // delete passes of the tiled layout this plan has seen
     float rate = 0.0f;                // growth of the displacement bound per substep, as the last tracked run measured it (0: not known)
     uint32_t fail_streak = 0;         // tracked runs refused in a row (each doubles the stretch of single substeps before the next look)
