@@ -34,9 +34,10 @@
  *         2.4 ms of its 2.4 ms (a Node host should call from a worker thread, as the
  *         reference itself does: engine.ts:138).  sb_delete_pass, sb_write_user_input
  *         and the sb_halo_* / sb_peer_* calls still only enqueue.
- *       A wait POLLS the stream for as long as the work in flight should take (at most
- *         8 ms) before it parks the thread: being woken costs 0.2 - 0.5 ms on some hosts,
- *         more than the wait itself.  SB_WAIT_SPIN_US=0 in the environment parks always.
+ *       A wait POLLS the stream for as long as the work in flight should take (busily for
+ *         the first 8 ms, then every ~50 us between short sleeps; 0.2 s at most) before it
+ *         parks the thread: being woken costs 0.2 - 0.5 ms on some hosts, more than many
+ *         of these waits.  SB_WAIT_SPIN_US=0 in the environment parks always.
  *   - there is no CPU fallback: without a usable HIP device sb_create fails.
  */
 #ifndef SOFTBODY_H

@@ -95,40 +95,42 @@ static void pool_trim(sb_engine *e)
 // thread, and being woken costs 20-50 us on a good day on this stack and several hundred on a bad one (r04: the lattice on the
 // floor, 32 looks and runs per 1000 substeps, read 28.5 us per substep on one box and 39-44 on another with every wait behind a
 // run parked) -- 10 % of the driver's 20-substep protocol at 1 M particles, and as much as the kernels of a small scene's frame.
-// Callers pass what the work in flight should take (default: a third of a millisecond); SB_WAIT_SPIN_US overrides every site
-// (0: always park).
+// Callers pass what the work in flight should take (default: a third of a millisecond; 0.2 s at most); SB_WAIT_SPIN_US overrides
+// every site (0: always park).
 static int64_t sb_spin_override()
 {
     static const int64_t v = [] { const char *s = getenv("SB_WAIT_SPIN_US"); return s ? (int64_t)atoll(s) : (int64_t)-1; }();
     return v;
 }
-static hipError_t sb_stream_wait(hipStream_t stream, int64_t spin_us = 330)
+// (three phases: busy polling for the first eight milliseconds, then a look every ~50 us between short sleeps -- a long grid-mode call
+// is found finished within a tenth of a millisecond without a core spinning for its 30 ms -- then the parking wait)
+template <typename Query, typename Park>
+static hipError_t sb_wait_phases(Query query, Park park, int64_t spin_us)
 {
     if (sb_spin_override() >= 0) spin_us = sb_spin_override();
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-        const hipError_t q = hipStreamQuery(stream);
+        const hipError_t q = query();
         if (q != hipErrorNotReady) return q;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > spin_us) break;
+        if (waited > 8000) {
+            std::this_thread::sleep_for(std::chrono::microseconds(40));
+        } else {
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
+        }
     }
-    return hipStreamSynchronize(stream);
+    return park();
+}
+static hipError_t sb_stream_wait(hipStream_t stream, int64_t spin_us = 330)
+{
+    return sb_wait_phases([&] { return hipStreamQuery(stream); }, [&] { return hipStreamSynchronize(stream); }, spin_us);
 }
 static hipError_t sb_event_wait(hipEvent_t ev, int64_t spin_us = 330)
 {
-    if (sb_spin_override() >= 0) spin_us = sb_spin_override();
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t q = hipEventQuery(ev);
-        if (q != hipErrorNotReady) return q;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-    }
-    return hipEventSynchronize(ev);
+    return sb_wait_phases([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); }, spin_us);
 }
 
 // SB_UPLOAD_TIMING=1: where sb_write_buffers spends its time (stderr), for tuning the host side of an upload
@@ -1526,7 +1528,7 @@ static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
             continue;
         }
         SB_HIP(e, hipMemcpyAsync(pin, e->d_grid_ctl, 2 * sizeof(SbGridCtl), hipMemcpyDeviceToHost, e->stream));
-        SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)chunk * (int64_t)(10u + e->P / 25000u), 8000)));
+        SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)chunk * (int64_t)(10u + e->P / 25000u), 200000)));
         if (!(pin[0].abort | pin[1].abort)) {
             m -= chunk;
             if (pin[e->grid_par].short_lived != 0u) { // hashes last four substeps or less: the classic schedule serves such a scene better
@@ -1685,6 +1687,9 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
             }
         }
         // ---- a run of tracked launches
+        // (48 launches a run at most: a run costs a look, two conversions and three waits whatever its length -- half a microsecond per
+        // substep of a 1 M-particle scene at 48 -- but runs of up to 240 launches measured SLOWER on the quiet lattice, 13.5 against
+        // 13.1 - 13.2 us per substep: r04)
         const uint32_t chunk = std::min<uint32_t>(std::min<uint32_t>(n, 48u * h.K), (uint32_t)std::min(0.8f * lasts, 1.0e6f));
         uint32_t ks[64], count = 0, k_hi = 0, n_hi = 0;
         const uint32_t L = sbk_split_call(chunk, h.K, false, &k_hi, &n_hi);
@@ -1711,7 +1716,7 @@ static sb_status hybrid_substeps(sb_engine *e, uint32_t n)
         sbk_hybrid_launch(e, ks, count, aux_last);
         SB_HIP(e, hipMemcpyAsync(pin, h.d_q + h.qpar, sizeof q, hipMemcpyDeviceToHost, e->stream)); // (... and the one its last validation wrote)
         // (the run is a few hundred microseconds to a few milliseconds of kernels, known in advance: poll for twice that)
-        SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)planned * (int64_t)(20u + e->P / 25000u), 8000)));
+        SB_HIP(e, sb_stream_wait(e->stream, std::min<int64_t>(400 + (int64_t)planned * (int64_t)(20u + e->P / 25000u), 200000)));
         q = *pin;
         const uint32_t done = std::min(q.done, count);
         // the host's idea of the buffers follows what the device really did

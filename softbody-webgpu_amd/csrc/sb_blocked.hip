@@ -77,8 +77,8 @@ struct SbBlockedState {
 struct SbTrack {
     // r04: a tracked launch VALIDATES THE LAUNCH BEFORE IT in its own prologue (the separate k_hybrid_validate launch behind every
     // tracked launch cost 4.6 us per six substeps; only the last launch of a run still gets one).  What a launch leaves for its
-    // successor: 64 slots {largest displacement sum by atomic max, the sample (dx, dy) of tiles 0 .. 63} + one flag word (a beam was
-    // flagged), triple buffered by launch number like the spatial hash's slots (sb_physics.h SbGridStep); the running state
+    // successor: 64 slots {largest displacement sum by atomic max, the sample (dx, dy) of tiles 0 .. 63; slot 0's fourth word: a beam was
+    // flagged}, triple buffered by launch number like the spatial hash's slots (sb_physics.h SbGridStep); the running state
     // (SbHybridCtl) in two blocks: every workgroup reads `q_in` and computes the verdict for itself -- one wave, 64 loads -- and
     // workgroup 0 writes the updated block `q_out` for the next launch.  Nothing is communicated inside a launch.
     const SbHybridCtl *q_in;
@@ -89,7 +89,7 @@ struct SbTrack {
     uint32_t *broken_prev;    // its break flags, waiting for the verdict (merged into `broken_ok` by the tiles that own the beams)
     uint32_t *broken_ok;
 };
-#define SB_HY_SLOTS 64u  // + one flag entry behind them
+#define SB_HY_SLOTS 64u  // (slot 0's fourth word: the launch flagged a beam)
 template <int MAT, bool AUX, bool PLAIN, bool TRACK>
 __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES, AUX ? SB_BK_WAVES_AUX : SB_BK_WAVES))) void k_substep_blocked(
     SbParticleArrays r, SbParticleArrays w, SbBlockedPlan bp, SbBlockedState bs, uint32_t k_run, const SbConsts c, SbParams prm,
@@ -101,22 +101,17 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     // TRACK: what the verdict on the launch before needs is REQUESTED here and consumed behind the acceleration / plastic flags
     // below, which are a trip to the L2 of their own anyway (consumed at once, the verdict put a second trip in front of every
     // workgroup's first request: +3.8 us per launch)
-    uint32_t hy_wv = 0u, hy_flagged = 0u;
+    uint32_t hy_wv = 0u;
     float4 hy_sl = make_float4(0.f, 0.f, 0.f, 0.f);
     if (TRACK) {
         // the verdict on the launch before this one, by every workgroup for itself (uniform: everybody reads the same words -- through
         // the VECTOR path, a word per lane: the launch before wrote them, and the scalar cache is not refreshed between launches)
         const uint32_t lane = threadIdx.x & 63u, nw = (uint32_t)(sizeof(SbHybridCtl) / 4u);
-        uint32_t wi = lane < nw ? lane : 0u;
-        asm volatile("" : "+v"(wi));
-        hy_wv = ((const uint32_t *)tr.q_in)[wi];
-        if (tr.slots_prev) {
-            uint32_t si = lane, fi = SB_HY_SLOTS;
-            asm volatile("" : "+v"(si), "+v"(fi));
-            hy_sl = tr.slots_prev[si];
-            hy_flagged = __float_as_uint(tr.slots_prev[fi].x);
-        }
-        if (blockIdx.x == 0u && threadIdx.x <= SB_HY_SLOTS) tr.slots_zero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (no inline asm up here to force the vector path: an asm statement in front of the tile-table loads counts as a store that
+        // may alias them, and they stop being scalar loads -- ten vector loads and their waits in every workgroup's first microsecond;
+        // the per-lane indices do it by themselves, and the flag rides in slot 0's fourth word)
+        hy_wv = ((const uint32_t *)tr.q_in)[lane < nw ? lane : 0u];
+        if (tr.slots_prev) hy_sl = tr.slots_prev[lane];
     }
     // static LDS layout: every address below is a register plus an immediate offset
     __shared__ float2 s_pos[SB_BK_CAP];
@@ -149,14 +144,19 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
     }
     const bool nb_plastic = __builtin_amdgcn_ballot_w64(nb_plastic_lane) != 0ull;
     if (TRACK) {
-        const uint32_t nw = (uint32_t)(sizeof(SbHybridCtl) / 4u);
-        SbHybridCtl q;
-        {
-            uint32_t *qw = (uint32_t *)&q;
-#pragma unroll
-            for (uint32_t i = 0; i < nw; i++) qw[i] = (uint32_t)__builtin_amdgcn_readlane((int)hy_wv, (int)i);
-        }
-        if (q.bad == 0u && tr.slots_prev) {
+        // (every word of the block into a SCALAR register by its own readlane: copied through a struct in private memory the words
+        // came back as vector values, the early return below became a divergent branch and every tile-table load behind it a
+        // vector load)
+        static_assert(sizeof(SbHybridCtl) == 44, "SbHybridCtl: eleven words, named below");
+#define SB_Q_U(i) ((uint32_t)__builtin_amdgcn_readlane((int)hy_wv, (i)))
+#define SB_Q_F(i) __uint_as_float(SB_Q_U(i))
+        float qD = SB_Q_F(0), qCx = SB_Q_F(1), qCy = SB_Q_F(2), qcx = SB_Q_F(3), qcy = SB_Q_F(4);
+        const float qskin = SB_Q_F(5);
+        uint32_t qbad = SB_Q_U(6), qdone = SB_Q_U(7), qsub = SB_Q_U(8);
+        const uint32_t qpad = SB_Q_U(9), qfail = SB_Q_U(10);
+#undef SB_Q_F
+#undef SB_Q_U
+        if (qbad == 0u && tr.slots_prev) {
             float m = hy_sl.x, sx = hy_sl.y, sy = hy_sl.z;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { // (a butterfly: the same sums in every wave of every workgroup)
@@ -167,28 +167,36 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
             m = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
             sx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sx)));
             sy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sy)));
-            const float D = q.D + m;
-            const bool ok = D <= q.skin && q.done != q.fail_at; // (NaN-safe; fail_at: the forced roll-back of the tests)
+            const float D = qD + m;
+            const bool ok = D <= qskin && qdone != qfail; // (NaN-safe; fail_at: the forced roll-back of the tests)
             if (!ok) {
-                q.bad = 1u;
+                qbad = 1u;
             } else {
                 const float ns = (float)min(bp.ntiles, SB_HY_SLOTS);
                 float mx = sb_div(sx, ns), my = sb_div(sy, ns); // (the drift this launch measures against: any estimate keeps the bound valid)
                 if (!(sb_abs(mx) < 1.0e30f) || !(sb_abs(my) < 1.0e30f)) mx = my = 0.0f;
-                q.D = D;
-                q.Cx += (float)tr.k_prev * q.cx; // (the drift the launch before measured against)
-                q.Cy += (float)tr.k_prev * q.cy;
-                q.cx = mx;
-                q.cy = my;
-                q.done += 1u;
-                q.substeps += tr.k_prev;
-                prev_broke = __builtin_amdgcn_readfirstlane(hy_flagged) != 0u;
+                qD = D;
+                qCx += (float)tr.k_prev * qcx; // (the drift the launch before measured against)
+                qCy += (float)tr.k_prev * qcy;
+                qcx = mx;
+                qcy = my;
+                qdone += 1u;
+                qsub += tr.k_prev;
+                prev_broke = __builtin_amdgcn_readlane((int)__float_as_uint(hy_sl.w), 0) != 0;
             }
         }
-        if (blockIdx.x == 0u && threadIdx.x == 0u) *tr.q_out = q;
-        if (q.bad != 0u) return; // (uniform; nothing has been written: the launches behind return the same way)
-        track_cx = q.cx;
-        track_cy = q.cy;
+        // (workgroup 0's two stores sit HERE, behind the tile-table loads: a global store in front of them makes them vector loads --
+        // the scalar cache is not coherent with this kernel's own stores, and the compiler cannot tell the arrays apart)
+        if (blockIdx.x == 0u && threadIdx.x < SB_HY_SLOTS) tr.slots_zero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.x == 0u && threadIdx.x == 0u) {
+            SbHybridCtl o;
+            o.D = qD; o.Cx = qCx; o.Cy = qCy; o.cx = qcx; o.cy = qcy; o.skin = qskin;
+            o.bad = qbad; o.done = qdone; o.substeps = qsub; o.pad_ = qpad; o.fail_at = qfail;
+            *tr.q_out = o;
+        }
+        if (qbad != 0u) return; // (uniform; nothing has been written: the launches behind return the same way)
+        track_cx = qcx;
+        track_cy = qcy;
     }
 
     if (TRACK && prev_broke) { // (rare) the flags the launch before raised on THIS tile's beams count now: into the mask the way back reads
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(SB_BK_T) __attribute__((amdgpu_waves_per_eu(AUX ? S
                 sb_store_wt(&bs.last_w[b0 + j], ls[i]);
                 if ((brk >> i) & 1u) {
                     atomicOr(&bs.broken[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
-                    if (TRACK) __hip_atomic_store((uint32_t *)&tr.slots_out[SB_HY_SLOTS].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (TRACK) __hip_atomic_store((uint32_t *)&tr.slots_out[0].w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
                 // a beam removed by a delete pass keeps its last state, which still has to travel to the other buffer: load,
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(64) void k_hybrid_validate(const float4 *__restrict
 {
     const uint32_t lane = threadIdx.x;
     const float4 sl = slots[lane];
-    const bool flagged = __float_as_uint(slots[SB_HY_SLOTS].x) != 0u;
+    const bool flagged = __builtin_amdgcn_readlane((int)__float_as_uint(sl.w), 0) != 0;
     SbHybridCtl q = *q_in;
     bool ok = false;
     if (q.bad == 0u) {
@@ -778,7 +786,7 @@ static void launch_one(sb_engine *e, SbBlockedDev &bk, uint32_t k, bool aux, boo
     SbTrack tr{};
     if (track) { // (launch number bk.seq: its slots, the block it reads and the one it writes, its own mask of break flags)
         float4 *slots = (float4 *)bk.d_hslots;
-        const uint32_t set = bk.seq % 3u, stride = SB_HY_SLOTS + 1u;
+        const uint32_t set = bk.seq % 3u, stride = SB_HY_SLOTS;
         tr.q_in = bk.d_q + bk.qpar;
         tr.q_out = bk.d_q + (bk.qpar ^ 1u);
         tr.slots_prev = bk.run_launches ? slots + ((bk.seq + 2u) % 3u) * stride : nullptr;
@@ -876,7 +884,7 @@ void sbk_hybrid_to_blocked(sb_engine *e)
                                                          h.d_target[h.cur ^ 1u], h.d_last[h.cur], h.d_plastic[0], h.d_plastic[1]);
     (void)hipMemsetAsync(h.d_broken, 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
     for (int b = 0; b < 2; b++) (void)hipMemsetAsync(h.d_broken_new[b], 0, (size_t)cdiv_b(B, 32) * 4, e->stream);
-    (void)hipMemsetAsync(h.d_hslots, 0, 3u * (SB_HY_SLOTS + 1u) * sizeof(float4), e->stream); // (a run starts from clean slots whatever ended the one before)
+    (void)hipMemsetAsync(h.d_hslots, 0, 3u * SB_HY_SLOTS * sizeof(float4), e->stream); // (a run starts from clean slots whatever ended the one before)
 }
 void sbk_hybrid_to_tiled(sb_engine *e, bool aux)
 {
@@ -895,7 +903,7 @@ void sbk_hybrid_launch(sb_engine *e, const uint32_t *ks, uint32_t count, bool au
     for (uint32_t i = 0; i < count; i++) launch_one(e, h, ks[i], aux_last && i + 1 == count, true);
     if (count) { // ... and the last one nobody behind it: the verdict on it by a launch of its own, into the block the host reads
         const uint32_t last = h.seq - 1u;
-        k_hybrid_validate<<<1, 64, 0, e->stream>>>((const float4 *)h.d_hslots + (last % 3u) * (SB_HY_SLOTS + 1u), h.ntiles, h.d_q + h.qpar,
+        k_hybrid_validate<<<1, 64, 0, e->stream>>>((const float4 *)h.d_hslots + (last % 3u) * SB_HY_SLOTS, h.ntiles, h.d_q + h.qpar,
                                                   h.d_q + (h.qpar ^ 1u), ks[count - 1], h.d_broken_new[last & 1u], h.d_broken, cdiv_b(h.nbeams, 32));
         h.qpar ^= 1u;
     }
