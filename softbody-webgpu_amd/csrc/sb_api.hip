@@ -2113,6 +2113,7 @@ sb_status sb_get_info(sb_engine *e, const char *key, uint64_t *value)
     else if (k == "hybrid_substeps") *value = e->hy.substeps_blocked; // substeps that ran blocked under SB_COLLIDE_GRID
     else if (k == "hybrid_launches") *value = e->hy.launches_ok;      // tracked launches that were validated
     else if (k == "hybrid_failed") *value = e->hy.launches_failed;    // tracked launches that went over the skin and were redone
+    else if (k == "hybrid_validate_launches") *value = e->hy.validate_launches; // k_hybrid_validate launches: one per run (a launch is validated by its successor's prologue)
     else if (k == "material_mode") *value = e->mat_mode;
     else if (k == "materials") *value = e->nmat;
     else if (k == "local_index_bits") *value = e->lbits;

@@ -906,6 +906,7 @@ void sbk_hybrid_launch(sb_engine *e, const uint32_t *ks, uint32_t count, bool au
         k_hybrid_validate<<<1, 64, 0, e->stream>>>((const float4 *)h.d_hslots + (last % 3u) * SB_HY_SLOTS, h.ntiles, h.d_q + h.qpar,
                                                   h.d_q + (h.qpar ^ 1u), ks[count - 1], h.d_broken_new[last & 1u], h.d_broken, cdiv_b(h.nbeams, 32));
         h.qpar ^= 1u;
+        h.validate_launches++;
     }
 }
 

@@ -97,7 +97,7 @@ struct SbBlockedDev {
     float rate = 0.0f;                // growth of the displacement bound per substep, as the last tracked run measured it (0: not known)
     uint32_t fail_streak = 0;         // tracked runs refused in a row (each doubles the stretch of single substeps before the next look)
     uint32_t slow_chunk = 0, slow_left = 0; // substeps to run substep by substep before looking again whether the scene is quiet (doubles while it is not)
-    uint64_t launches_ok = 0, launches_failed = 0, substeps_blocked = 0;
+    uint64_t launches_ok = 0, launches_failed = 0, substeps_blocked = 0, validate_launches = 0; // (validate_launches: k_hybrid_validate launches -- one per run since r04)
     uint32_t k_long = 0;      // substeps per launch of a long call (what the traffic model prices)
     bool fixed_depth = false; // the caller named the depth (sb_options.block_substeps): every call runs in the fewest launches
     uint64_t entries = 0, halo_entries = 0, halo_particles = 0; // totals of the whole plan (depth K)

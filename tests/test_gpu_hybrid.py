@@ -28,7 +28,8 @@ def run(sb, oracle, buf, *, bounds, n=0, frames=0, calls=1, ref_mode=None, subti
         eng.step(n)
         ref.step(n)
     got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
-    info = {k: eng.info(k) for k in ("hybrid", "hybrid_substeps", "hybrid_failed", "grid_builds", "substeps_done")}
+    info = {k: eng.info(k) for k in ("hybrid", "hybrid_substeps", "hybrid_failed", "grid_builds", "substeps_done", "hybrid_launches",
+                                     "hybrid_validate_launches")}
     eng.destroy()
     return got, exp, info
 
@@ -40,6 +41,8 @@ def test_quiet_lattice_runs_blocked_and_matches_the_oracle(sb, oracle):
     got, exp, info = run(sb, oracle, buf, bounds=6000.0, n=150, calls=2)
     assert info["hybrid"] >= 2 and info["substeps_done"] == 300
     assert info["hybrid_substeps"] >= 200, info
+    # r04: a tracked launch is validated by the prologue of the launch behind it; only the last launch of a run gets a launch for it
+    assert info["hybrid_launches"] >= 30 and info["hybrid_validate_launches"] * 4 <= info["hybrid_launches"], info
     assert_same(got, exp, "quiet lattice, hybrid")
     _, off, _ = run(sb, oracle, buf, bounds=6000.0, n=150, calls=2, ref_mode=OFF)
     assert_same(got, off, "quiet lattice == collisions off")
