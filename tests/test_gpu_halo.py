@@ -481,3 +481,74 @@ def test_repartition_on_engines_follows_two_clouds_through_each_other(sb):
     assert np.array_equal(gbuf.particles[:P].view("u4"), want.particles[:P].view("u4"))       # gbuf IS the gathered state now
     assert sum(p.ghost_p.size for _, plan in made for p in plan.peers) > 40
 
+
+
+@pytest.mark.parametrize("world,depth,mode", [(2, 5, 0), (2, 6, 2)])
+def test_ghost_zones_on_engines_that_kept_their_plan_through_a_cut(sb, world, depth, mode):
+    """r04: an upload that only removed beams keeps the plan, and the caller's beam slots map onto the engine's (sb_engine.h
+    h_user_slot).  sb_halo_configure names beams by DATA index: here every rank first holds its slab plus forty extra beams in the
+    middle of the slot order, then receives the slab itself (the forty cut, another beam mapping), and only then its ghost lists --
+    the merged run must still equal the single engine's, bit for bit."""
+    import torch
+    from halo_oracle import LocalBus, step_all
+    halo = sb.halo
+    W, H, steps, extra = 40, 48, 60, 40
+    kw = dict(d=30.0, origin=(100.0, 11.5), jitter=1.0, velocity=(0.3, -4.0), strain_limit=0.5, yield_strain=0.2)
+    bounds = 8000.0
+
+    def engine_for(buf, cut_first):
+        big = sb.Buffers(2, buf.max_particles, buf.max_beams + extra)
+        P, B = buf.particle_count, buf.beam_count
+        big.set_scene(buf.particles[:P], buf.beams[:B])                 # identity mapping: data index == slot, as in `buf`
+        big.metadata[:] = buf.metadata
+        big.metadata[11] = big.max_beams                                 # (MD_MAX_BEAMS)
+        e = sb.Engine(bounds_size=bounds, layout=2, max_particles=big.max_particles, max_beams=big.max_beams, collision_mode=mode,
+                      tile_particles=256)
+        if cut_first:
+            sup = big.copy()
+            sup.beams[B:B + extra] = big.beams[:extra]                   # forty more beams (copies of the first forty, softer) ...
+            sup.beams["spring"][B:B + extra] *= np.float32(0.5)
+            m, maxP, at = sup.mapping, sup.max_particles, B // 2
+            m[maxP:maxP + B + extra] = np.concatenate([np.arange(at), np.arange(B, B + extra), np.arange(at, B)])   # ... in the middle of the slot order
+            sup.beam_count = B + extra
+            e.write_buffers(sup)
+            e.step(3)
+        e.write_buffers(big)
+        assert e.info("uploads_edited") == (1 if cut_first else 0)
+        return e, big
+
+    gbuf, gplan = halo.slab_scene(sb, 0, 1, W * world, H, depth=depth, **kw)
+    ref, gbig = engine_for(gbuf, False)
+    ref.step(steps)
+    want = ref.load_buffers(gbig.copy())
+    ref.destroy()
+
+    dev = torch.device("cuda", 0)
+    bus = LocalBus()
+    exs, made = [], []
+    for r in range(world):
+        buf, plan = halo.slab_scene(sb, r, world, W, H, depth=depth, **kw)
+        eng, big = engine_for(buf, True)
+        tr = bus.transport(r, lambda a, b: (torch.zeros(max(a, 1), device=dev), torch.zeros(max(b, 1), device=dev)),
+                           lambda t: t.data_ptr())
+        exs.append(halo.Exchanger(eng, plan, tr))
+        made.append((big, plan, eng))
+
+    def sync():
+        for _, _, e in made:
+            e.sync()
+        torch.cuda.synchronize()
+
+    step_all(exs, bus, steps, lambda dst, src: dst.copy_(src), sync)
+    parts = np.zeros_like(want.particles)
+    beams = {}
+    for big, plan, eng in made:
+        out = eng.load_buffers(big.copy())
+        gid, prt, bkey, brec = halo.gather_owned(plan, out)
+        parts[gid] = prt
+        for k, rec in zip(bkey, brec):
+            beams[int(k)] = rec.tobytes()[8:]
+        eng.destroy()
+    assert np.array_equal(parts.view("u4"), want.particles.view("u4"))
+    for k, rec in zip(gplan.global_beam_key, want.beams):
+        assert beams[int(k)] == rec.tobytes()[8:]
