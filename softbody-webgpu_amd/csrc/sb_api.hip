@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 #include "sb_engine.h"
+#include "sb_edit.h"
 
 extern "C" sb_status sb_halo_set_layout(sb_engine *e, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *);
 
@@ -765,38 +766,18 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
         if (!same.load()) return SB_OK;
         user_slot = e->h_user_slot;
     } else {
-        // Beams were removed: the records that are left are a subsequence of the old ones (Map order, engineMapping.ts:510).  Any
-        // strictly increasing match of equal records will do.  In chunks: where each chunk starts in the old list is found one
-        // chunk after the other (the shift only grows, by the beams removed in between), the chunks are then matched side by side.
-        const size_t chunk = 1 << 15, nch = (B + chunk - 1) / chunk;
-        std::vector<uint32_t> start(nch + 1, Bu);
-        uint32_t op = 0;
-        for (size_t k = 0; k < nch && same.load(std::memory_order_relaxed); k++) {
-            const size_t u0 = k * chunk;
-            op = std::max<uint32_t>(op, (uint32_t)u0);
-            const uint8_t *rec = bd + (size_t)map_get(e, mp, (size_t)maxP + u0) * bstride;
+        // Beams were removed: the records that are left are a subsequence of the old ones (sb_edit.h)
+        auto same_key = [&](size_t u, size_t o) {
+            const uint8_t *rec = bd + (size_t)map_get(e, mp, (size_t)maxP + u) * bstride;
             const uint32_t a = v1 ? rd_u32(rec) & 0xffffu : rd_u32(rec), b = v1 ? rd_u32(rec) >> 16 : rd_u32(rec + 4);
-            while (op < Bu && (size_t)op - u0 <= (size_t)(Bu - B) && !(e->h_beams[sb_user_slot(e, op)].da == a && e->h_beams[sb_user_slot(e, op)].db == b)) op++;
-            if (op >= Bu || (size_t)op - u0 > (size_t)(Bu - B)) same.store(false, std::memory_order_relaxed);
-            start[k] = op;
-        }
-        if (!same.load()) return SB_OK;
+            const SbHostBeam &h = e->h_beams[sb_user_slot(e, o)];
+            return h.da == a && h.db == b;
+        };
+        std::vector<uint32_t> old_of_new;
+        if (!sbe::match_subsequence(B, Bu, (size_t)1 << 15, same_key, [&](size_t u, size_t o) { return take(u, sb_user_slot(e, o)); }, old_of_new))
+            return SB_OK;
         user_slot.resize(B);
-        sbt::parallel_ranges(nch, 1, [&](size_t k0, size_t k1) {
-            for (size_t k = k0; k < k1 && same.load(std::memory_order_relaxed); k++) {
-                uint32_t o = start[k];
-                const size_t u1 = std::min<size_t>((k + 1) * chunk, B);
-                for (size_t u = k * chunk; u < u1; u++) {
-                    while (o < start[k + 1] && !take(u, sb_user_slot(e, o))) o++;
-                    if (o >= start[k + 1]) { // (ran into the next chunk's beams, or off the end)
-                        same.store(false, std::memory_order_relaxed);
-                        return;
-                    }
-                    user_slot[u] = sb_user_slot(e, o++);
-                }
-            }
-        });
-        if (!same.load()) return SB_OK;
+        for (uint32_t u = 0; u < B; u++) user_slot[u] = sb_user_slot(e, old_of_new[u]);
     }
     tm.mark("same topology: mapping + beam records");
     std::vector<float2> hp(P), hv(P), ha(P);

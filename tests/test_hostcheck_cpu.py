@@ -1,7 +1,7 @@
 """The host side of the C library under sanitizers (`make -C softbody-webgpu_amd/csrc hostcheck`): the scene
 partitioner (csrc/sb_partition.cpp, driven by tests/partition_check.cpp on the reference's default scene, main.ts:188-246, and
 on a 90 000-particle lattice, v1 and v2 layouts) and the two multi-threaded upload planners (sb_tiling.h, sb_blocking.h with the
-check drivers of tests/test_tiling_cpu.py / test_blocking_cpu.py), each built with AddressSanitizer + UBSan and with
+check drivers of tests/test_tiling_cpu.py / test_blocking_cpu.py) and the subsequence matcher of edit uploads (sb_edit.h), each built with AddressSanitizer + UBSan and with
 ThreadSanitizer.  CPU only: the GPU pool has no sanitizers."""
 import os
 import subprocess
@@ -61,3 +61,12 @@ def test_planners_under_sanitizers(built, san):
         assert "BLOCKING_OK" in run(os.path.join(built, "blocking_check_" + san), args)
     for args in (("100", "80", "1024", "1", "0"), ("60", "50", "256", "4", "1"), ("300", "300", "1024", "5", "0")):
         assert "TILING_OK" in run(os.path.join(built, "tiling_check_" + san), args)
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_subsequence_matcher_under_sanitizers(built, san):
+    """csrc/sb_edit.h, the matcher behind uploads that only removed beams (r04): 300 random lists with long runs of equal keys, cuts of
+    0 - 12 %, chunks of 8 - 256 records matched side by side on host threads -- every valid list matched (strictly increasing, equal
+    records, the new record's state taken over), every spoiled list refused."""
+    out = run(os.path.join(built, "edit_check_" + san), ["300"])
+    assert "300 lists matched, 0 refused, 300 spoiled lists refused" in out, out
