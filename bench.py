@@ -650,6 +650,26 @@ def run_workload(ctx, a, W, H, subticks, mixed, mode, steps, warmup, named=None,
         t0 = time.perf_counter()
         eng.load_buffers(out)
         rec["readback_ms"] = (time.perf_counter() - t0) * 1e3
+        if not a.no_extra:   # uploads that keep the plan: the state just read back (same topology), and that state with 1 % of the beams cut
+            import numpy as np
+            t0 = time.perf_counter()
+            eng.write_buffers(out)
+            same_ms = (time.perf_counter() - t0) * 1e3
+            B, maxP = out.beam_count, out.max_particles
+            keep = np.random.default_rng(1).random(B) >= 0.01
+            cut = out.copy()
+            recs = out.beams[out.mapping[maxP:maxP + B].astype(np.int64)][keep]
+            cut.beams[:len(recs)] = recs
+            cut.mapping[maxP:maxP + len(recs)] = np.arange(len(recs))
+            cut.beam_count = len(recs)
+            t0 = time.perf_counter()
+            eng.write_buffers(cut)
+            cut_ms = (time.perf_counter() - t0) * 1e3
+            rec["reupload"] = {"same_topology_ms": same_ms, "beams_cut_ms": cut_ms, "beams_cut": int(B - len(recs)),
+                               "plan_kept": [int(eng.info("uploads_kept")), int(eng.info("uploads_edited"))],
+                               "note": "sb_write_buffers on the engine that holds the scene: the state just read back (same topology: only "
+                                       "state travels), then that state with 1 % of its beams removed (the plan is kept, the removed beams "
+                                       "die on the device); plan_kept = [uploads that kept the plan, of them uploads that removed beams]"}
     eng.destroy()
     rec["cpu_baseline"] = None
     if want_cpu and rank == 0 and not a.no_cpu_baseline:
@@ -737,6 +757,8 @@ def main():
             line["config"]["exchange"] = rec["exchange"]
         extra = {}
         if world == 1:
+            if rec.get("reupload"):
+                extra["reupload"] = rec["reupload"]
             extra.update({"upload_ms": rec["upload_ms"], "readback_ms": rec.get("readback_ms"),
                           "upload_note": "sb_write_buffers / sb_load_buffers of the whole scene, host buffers <-> HBM, "
                                          "tiling and AoS<->SoA transposes included; never part of `value`"})

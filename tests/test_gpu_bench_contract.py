@@ -52,6 +52,9 @@ def test_default_line_carries_the_contract():
     assert d["value"] > 1.0e10                                   # BASELINE's target for config 2
     ex = d["extra"]
     assert ex["upload_ms"] > 0 and ex["readback_ms"] > 0 and ex["config3"]["value"] > 1.0e10 and ex["config3"]["finite"]
+    # uploads that keep the plan (r04: also when beams were only removed): both kept, both far below the upload that plans
+    ru = ex["reupload"]
+    assert ru["plan_kept"] == [2, 1] and ru["beams_cut"] > 20000 and ru["same_topology_ms"] < 40.0 and ru["beams_cut_ms"] < 40.0 < ex["upload_ms"]
     check_roofline(ex["config3"]["roofline"], blocked=False, lists=True)
     assert ex["config3"]["hash_schedule"]["grid_helper_launches"] == 0      # every hash pushed by the substep kernels themselves
     assert "r0" in ex["config3"]["contacts"] and "config3_contacts_check.txt" in ex["config3"]["contacts"]
