@@ -686,6 +686,15 @@ sb_status sb_destroy(sb_engine *e)
     return SB_OK;
 }
 
+// Test hook (tests/test_gpu_grid_schedule.py; read once per process): the count of executed substeps an upload starts from.  The
+// device counts in 32 bits, the host picks the slot set by count % 3: SB_GRID_EXECUTED0=4294967200 puts the wrap a hundred
+// substeps behind every upload (r04: the host count is 64 bits wide since; it used to wrap out of step with the sets).
+static inline uint32_t sb_grid_executed0()
+{
+    static const uint32_t v = [] { const char *s = getenv("SB_GRID_EXECUTED0"); return s ? (uint32_t)strtoull(s, nullptr, 10) : 0u; }();
+    return v;
+}
+
 // the caller's beam slots (those of the latest upload) -> the engine's own (sb_engine.h h_user_slot)
 static inline uint32_t sb_user_beams(const sb_engine *e) { return e->h_user_slot.empty() ? e->B : (uint32_t)e->h_user_slot.size(); }
 static inline uint32_t sb_user_slot(const sb_engine *e, size_t u) { return e->h_user_slot.empty() ? (uint32_t)u : e->h_user_slot[u]; }
@@ -904,7 +913,8 @@ static sb_status rewrite_scene_state(sb_engine *e, const uint8_t *md, const uint
         SB_HIP(e, hipMemcpyAsync(e->d_grid_ctl, e->grid_ctl0, sizeof e->grid_ctl0, hipMemcpyHostToDevice, e->stream));
         e->grid_par = 0;
         e->grid_force = true;
-        e->grid_classic_left = e->grid_classic_chunk = e->grid_calm = e->grid_executed = 0;
+        e->grid_classic_left = e->grid_classic_chunk = e->grid_calm = 0;
+        e->grid_executed = sb_grid_executed0();
     }
     memcpy(&e->consts, md + 48, sizeof(SbConsts));
     SB_HIP(e, hipStreamSynchronize(e->stream));
@@ -1362,6 +1372,7 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
             ctl[k].geo.reach2 = reach * reach * 1.001f;
             ctl[k].pgeo = ctl[k].geo;
             ctl[k].since = 1000; // "the hash before the first one lasted long": start lean
+            ctl[k].executed = sb_grid_executed0();
         }
         SB_HIP(e, hipMemcpy(e->d_grid_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
         memcpy(e->grid_ctl0, ctl, sizeof ctl);
@@ -1369,7 +1380,8 @@ static sb_status sb_write_buffers_impl(sb_engine *e, const void *metadata, size_
         e->grid_slots = 3 * SB_GRID_SLOTS * 4;
         e->grid_par = 0;
         e->grid_force = true; // no hash yet: the first substep starts with a forced helper launch
-        e->grid_classic_left = e->grid_classic_chunk = e->grid_calm = e->grid_executed = 0;
+        e->grid_classic_left = e->grid_classic_chunk = e->grid_calm = 0;
+        e->grid_executed = sb_grid_executed0();
         e->grid.head = e->d_head[0];
         e->grid.rec = e->d_rec[0];
         e->grid.cell_of = e->d_cell_of[0];
@@ -1490,7 +1502,8 @@ static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
     while (m) {
         const uint32_t sched = sbk_grid_mode(e);
         const bool stretch = sched == SB_GRID_CLASSIC && e->grid_classic_left != 0u;
-        const uint32_t chunk = stretch ? std::min(m, e->grid_classic_left) : m, exec0 = e->grid_executed;
+        const uint32_t chunk = stretch ? std::min(m, e->grid_classic_left) : m;
+        const uint64_t exec0 = e->grid_executed;
         for (uint32_t i = 0; i < chunk; i++) sbk_launch_substep(e, aux_on_last && i + 1 == m);
         SbGridCtl *pin = (SbGridCtl *)(e->dev_err + 96); // (pinned; hybrid_substeps uses words 16 .. 95)
         if (sched == SB_GRID_CLASSIC) { // (its decisions never abort: the helper serves whatever they order)
@@ -1526,7 +1539,9 @@ static sb_status grid_substeps(sb_engine *e, uint32_t m, bool aux_on_last)
             continue;
         }
         // the launches that ran are the ones that counted themselves; the rest returned at once
-        const uint32_t reached = std::max(pin[0].executed, pin[1].executed), ran = std::min(reached - exec0, chunk), undone = chunk - ran;
+        // (the device counts in 32 bits: how far the two blocks are AHEAD of where this call started, wrap or no wrap)
+        const int32_t ahead = std::max((int32_t)(pin[0].executed - (uint32_t)exec0), (int32_t)(pin[1].executed - (uint32_t)exec0));
+        const uint32_t ran = std::min<uint32_t>((uint32_t)std::max(ahead, 0), chunk), undone = chunk - ran;
         static const bool debug = getenv("SB_GRID_DEBUG") != nullptr;
         if (debug) fprintf(stderr, "[sb grid] abort after %u of %u substeps (classic stretch %u)\n", ran, chunk, std::max(16u, 2u * e->grid_classic_chunk));
         e->cur ^= undone & 1u;

@@ -797,7 +797,7 @@ static void launch_one(sb_engine *e, SbBlockedDev &bk, uint32_t k, bool aux, boo
         tr.broken_ok = bk.d_broken;
         bs.broken = bk.d_broken_new[bk.seq & 1u]; // (merged into bk.d_broken by the launch behind it, or by k_hybrid_validate)
         bk.qpar ^= 1u;
-        bk.seq++;
+        bk.seq = (bk.seq + 1u) % 6u; // (its parity picks a mask of break flags, its remainder by 3 a set of slots: a counter that never wraps out of step)
         bk.run_launches++;
         bk.k_prev = k;
     }
@@ -902,7 +902,7 @@ void sbk_hybrid_launch(sb_engine *e, const uint32_t *ks, uint32_t count, bool au
     h.run_launches = 0; // (the first launch of a run has nobody to validate)
     for (uint32_t i = 0; i < count; i++) launch_one(e, h, ks[i], aux_last && i + 1 == count, true);
     if (count) { // ... and the last one nobody behind it: the verdict on it by a launch of its own, into the block the host reads
-        const uint32_t last = h.seq - 1u;
+        const uint32_t last = (h.seq + 5u) % 6u; // (the launch before the next one)
         k_hybrid_validate<<<1, 64, 0, e->stream>>>((const float4 *)h.d_hslots + (last % 3u) * SB_HY_SLOTS, h.ntiles, h.d_q + h.qpar,
                                                   h.d_q + (h.qpar ^ 1u), ks[count - 1], h.d_broken_new[last & 1u], h.d_broken, cdiv_b(h.nbeams, 32));
         h.qpar ^= 1u;

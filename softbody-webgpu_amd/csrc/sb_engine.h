@@ -209,7 +209,7 @@ struct sb_engine {
     bool grid_force = false;          // the next substep starts with a forced helper launch (upload, ghost refresh, hybrid, abort recovery)
     uint32_t grid_classic_left = 0, grid_classic_chunk = 0; // substeps left in the classic stretch after an abort; its length (doubles per abort, decays when calm)
     uint32_t grid_calm = 0;           // lagged substeps since the last abort
-    uint32_t grid_executed = 0;       // host mirror of SbGridCtl::executed: single substeps run since the upload
+    uint64_t grid_executed = 0;       // host mirror of SbGridCtl::executed (which wraps at 2^32; this one picks the slot set, k % 3, and must not): single substeps run since the upload
     uint64_t grid_aborts = 0, grid_helper_launches = 0, grid_classic_substeps = 0; // statistics (sb_get_info)
     uint32_t *dev_err = nullptr;      // pinned host word: bounded device-side waits report here (sb_sync reads it)
     // pinned staging of uploads and read-backs (sb_api.hip: stage_*): two chunks, filled / drained by several host threads while

@@ -828,7 +828,8 @@ uint32_t sbk_grid_mode(const sb_engine *e)
 // what a launch that decides needs: the control blocks and the displacement slots by the number of the substep it is (or is in front of)
 static SbGridStep sbk_grid_step(const sb_engine *e, uint32_t sched)
 {
-    const uint32_t nblk = e->path == SB_PATH_TILED ? e->ntiles : cdiv(e->P, SB_BLOCK), k = e->grid_executed; // substeps run so far
+    const uint32_t nblk = e->path == SB_PATH_TILED ? e->ntiles : cdiv(e->P, SB_BLOCK);
+    const uint64_t k = e->grid_executed; // substeps run so far (64 bits: k % 3 has to go on across 2^32 substeps, two days of a busy engine)
     float4 *slots = (float4 *)e->d_blk_max;
     SbGridStep st{e->d_grid_ctl, e->grid_par, sched, slots + (size_t)(k % 3u) * SB_GRID_SLOTS, slots + (size_t)((k + 1u) % 3u) * SB_GRID_SLOTS,
                   slots + (size_t)((k + 2u) % 3u) * SB_GRID_SLOTS, 1.0f / (float)std::min<uint32_t>(std::max(nblk, 1u), SB_GRID_SLOTS), e->d_grid_outside, e->P};

@@ -226,3 +226,53 @@ def test_classic_schedule_forced(sb):
     env = dict(os.environ, SB_GRID_MODE="classic", SB_HYBRID="0", GRAFT_REPO_ROOT=ROOT)
     p = subprocess.run([sys.executable, "-c", CLASSIC], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "CLASSIC_OK" in p.stdout, p.stdout + p.stderr
+
+
+WRAP = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "oracle"))
+sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "tests"))
+import __graft_entry__ as ge
+import oracle
+sb = ge.load_package()
+# 1. a pile across the wrap (the device's 32-bit count of substeps passes 2^32 at substep 46): same bits as the oracle's grid mode
+pile, bounds = sb.scenes.blob_pile_buffers(8, 4, gap=19.6)
+eng = sb.Engine(bounds_size=bounds, layout=2, max_particles=pile.max_particles, max_beams=pile.max_beams, collision_mode=2, tile_particles=128)
+ref = oracle.OracleEngine(bounds, 10.0, 64, 2, 2, threads=8)
+eng.write_buffers(pile); ref.write_buffers(pile)
+for n in (30, 30, 64, 100):
+    eng.step(n); ref.step(n)
+    got, exp = eng.load_buffers(pile.copy()), ref.load_buffers(pile.copy())
+    assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4")) and got.beams.tobytes() == exp.beams.tobytes(), n
+assert eng.info("grid_builds") >= 3 and eng.info("grid_helper_launches") <= 1
+eng.destroy()
+# 2. a kick that makes a launch abort right behind the wrap: the host's roll-back counts across it
+buf = sb.scenes.soup_buffers(36, 36, d=44.0, origin=(40.0, 40.0), jitter=6.0, speed=6.0, seed=9)
+eng = sb.Engine(bounds_size=1800.0, layout=2, max_particles=buf.max_particles, max_beams=buf.max_beams, collision_mode=2, tile_particles=128)
+ref = oracle.OracleEngine(1800.0, 10.0, 64, 2, 1, threads=16)
+eng.write_buffers(buf); ref.write_buffers(buf)
+eng.step(40); ref.step(40)
+ui = np.zeros(8, "f4"); ui[0] = 1.0; ui[6], ui[7] = 9000.0, 2700.0
+eng.write_user_input(ui.tobytes()); ref.write_user_input(ui.tobytes())
+eng.step(2); ref.step(2)
+ui[6] = ui[7] = 0.0
+eng.write_user_input(ui.tobytes()); ref.write_user_input(ui.tobytes())
+eng.step(70); ref.step(70)
+got, exp = eng.load_buffers(buf.copy()), ref.load_buffers(buf.copy())
+assert np.isfinite(exp.particles).all()
+assert np.array_equal(got.particles.view("u4"), exp.particles.view("u4"))
+assert eng.info("grid_aborts") >= 1 and eng.info("substeps_done") == 112
+print("WRAP_OK", eng.info("grid_aborts"))
+"""
+
+
+def test_the_substep_count_wraps_without_a_trace():
+    """The device counts executed substeps in 32 bits; the host picks the set of displacement slots by its own count modulo 3 and
+    rolls back after an abort by the difference of the two.  SB_GRID_EXECUTED0 (a test hook, read once per process) starts every
+    upload 46 substeps short of 2^32 -- two days of a busy engine: a pile and a kicked gas cross the wrap bit for bit (until r04 the
+    host's count was 32 bits wide too, and 2^32 is not a multiple of 3)."""
+    env = dict(os.environ, SB_GRID_EXECUTED0=str(2 ** 32 - 46), SB_HYBRID="0", GRAFT_REPO_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-c", WRAP], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "WRAP_OK" in p.stdout, p.stdout + p.stderr
